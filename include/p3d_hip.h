@@ -1,0 +1,130 @@
+/* libp3dhip -- C ABI of the MI355X-native P3D saliency forward/backward path.
+ *
+ * The reference (A-Nasiri-M/sap3d_tensorflow) has no FFI layer: its boundary is the Python
+ * graph function  p3d.p3d_unet(_X, _dropout, batch_size, training)  (reference p3d.py:169) plus
+ * the tf.Session feed/fetch contract its drivers use (train.py:143-146,217-218,225-226;
+ * gen_pred.py:45-46,151).  Each entry point below names the reference interface it replaces.
+ * The binding a maintainer adds on the reference side is a ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a
+ * negative code on failure with the message available from p3d_last_error(); host buffers are
+ * owned by the caller and copied by value (like feed_dict / fetched numpy arrays); device
+ * memory, streams and RCCL state are owned by the opaque handle; one caller thread per handle
+ * (like the single thread calling sess.run).  All tensors are float32 NDHWC.
+ */
+#ifndef P3D_HIP_H
+#define P3D_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct p3d_handle p3d_handle;
+
+enum { P3D_STRUCTURE_UNET = 0 };      /* train.py:149-150  --structure unet -> p3d.p3d_unet */
+
+typedef struct p3d_config {
+    int structure;        /* P3D_STRUCTURE_*                                                    */
+    int batch;            /* clips per step on THIS device (placeholder dim 0, train.py:143)    */
+    int frames;           /* 16 in the reference (train.py:139, p3d.py:5); multiple of 16        */
+    int height, width;    /* 112 in the reference (p3d.py:4); multiples of 16                   */
+    int base;             /* stem width; 64 in the reference (p3d.py:172,179,185,191)           */
+    int blocks[3];        /* bottlenecks per stage; 3,8,36 in the reference (p3d.py:179,185,191) */
+    int device;           /* HIP device ordinal (train.py:73 CUDA_VISIBLE_DEVICES=args.gpu)      */
+    int world_size;       /* data-parallel replicas (1 = the reference's single device)          */
+    int rank;
+} p3d_config;
+
+/* Fill *cfg with the reference architecture: unet, batch 2, 16x112x112, base 64, blocks 3/8/36. */
+void p3d_default_config(p3d_config* cfg);
+
+/* Builds the graph once, like the graph-construction part of train.py:143-172 / gen_pred.py:45-46. */
+int p3d_create(const p3d_config* cfg, p3d_handle** out);
+void p3d_destroy(p3d_handle* h);
+const char* p3d_last_error(void);
+
+/* ---- variables: tf.global_variables(), Saver var_list (train.py:180-185).  Names are the TF
+ *      variable names (firstconv1, conv3_0_1, STA_0_2_S, STA_0_2_S_bias, dw3d_0,
+ *      batch_normalization_7/gamma, .../moving_mean, conv3d_transpose/kernel, deconv1_bn/beta ...). */
+int p3d_num_params(p3d_handle* h);
+int p3d_param_info(p3d_handle* h, int index, const char** name, int* ndim, int64_t shape[5], int* trainable);
+int p3d_set_param(p3d_handle* h, const char* name, const float* host, int64_t count);   /* saver.restore */
+int p3d_get_param(p3d_handle* h, const char* name, float* host, int64_t count);         /* saver.save    */
+int p3d_get_grad(p3d_handle* h, const char* name, float* host, int64_t count);          /* tf.gradients (parity hook) */
+/* tf.global_variables_initializer (train.py:178): Xavier-uniform etc., SURVEY.md Appendix A.7. */
+int p3d_init_params(p3d_handle* h, uint64_t seed);
+
+/* ---- sess.run(pred, {x, dropout: 0, training: False})   train.py:225-226, gen_pred.py:151.
+ *      x [B,T,H,W,3] -> pred [B,T,H,W,1].  `training` is the placeholder of train.py:145: it
+ *      switches stem/decoder BN and dropout only; backbone BN always uses batch statistics
+ *      (p3d.py:140,179,185,191).  Never updates moving statistics (UPDATE_OPS are not fetched). */
+int p3d_forward(p3d_handle* h, const float* x, int training, float dropout_rate, uint64_t seed, float* pred);
+
+/* ---- sess.run([train_op, loss], {x, y, dropout, training: True})   train.py:217-218.
+ *      y [B,T,H,W]; Smooth-L1 SUM loss (utils/network.py:49-62), Adam on every trainable
+ *      (train.py:168), BN moving-average updates (train.py:170-172).  With world_size > 1 the
+ *      gradients are summed across replicas (RCCL) before Adam. */
+int p3d_train_step(p3d_handle* h, const float* x, const float* y, float dropout_rate, uint64_t seed, float* loss);
+
+/* Parity hook: forward (training=True) + loss + backward, no Adam, no moving-stat update.
+ * pred may be NULL.  Gradients are then readable with p3d_get_grad. */
+int p3d_backward(p3d_handle* h, const float* x, const float* y, float dropout_rate, uint64_t seed,
+                 float* loss, float* pred);
+
+/* tf.train.AdamOptimizer(lr, beta1, beta2, epsilon) (train.py:168; defaults 1e-4, .9, .999, 1e-8). */
+int p3d_set_adam(p3d_handle* h, float lr, float beta1, float beta2, float eps);
+
+/* ---- intermediate tensors (tf fetches of graph tensors; parity/debug taps).  Names:
+ *      conv1_custom, conv1_custom_bn_relu, pool1..pool4, block<i>/conv1_bn_relu, block<i>/st,
+ *      block<i>/out, deconv3_re, deconv4_conv1, logits, pred. */
+int p3d_activation_info(p3d_handle* h, const char* name, int64_t shape[5]);
+int p3d_get_activation(p3d_handle* h, const char* name, float* host, int64_t count);
+
+/* ---- device-resident stepping for measurement: inputs already in HBM (bench.py).
+ *      p3d_device_inputs returns the handle's own x / y staging buffers (device pointers,
+ *      [B,T,H,W,3] and [B,T,H,W] floats); fill them once with p3d_upload_inputs, then call
+ *      p3d_train_step_device / p3d_forward_device repeatedly; p3d_synchronize drains the stream. */
+int p3d_upload_inputs(p3d_handle* h, const float* x, const float* y);
+int p3d_train_step_device(p3d_handle* h, float dropout_rate, uint64_t seed);
+int p3d_forward_device(p3d_handle* h, int training, float dropout_rate, uint64_t seed);
+int p3d_last_loss(p3d_handle* h, float* loss);          /* synchronises */
+int p3d_synchronize(p3d_handle* h);
+
+/* ---- per-op timing of one train step with HIP events on the compute stream (the data behind
+ *      bench.py's roofline object).  Writes up to `cap` records; returns the number of ops. */
+typedef struct p3d_op_time {
+    char name[64];
+    char kind[24];        /* kernel family */
+    double ms;            /* HIP-event duration of the op's launches */
+    double flops;         /* algorithmic FLOPs (2*MACs) */
+    double bytes;         /* algorithmic HBM bytes (operands read once, result written once) */
+    int backward;         /* 0 forward op, 1 backward op, 2 optimiser */
+} p3d_op_time;
+int p3d_profile_step(p3d_handle* h, float dropout_rate, uint64_t seed, p3d_op_time* out, int cap);
+
+/* ---- data parallel (no reference counterpart: the reference is single-device, train.py:73).
+ *      Rank 0 creates an id, every rank passes the same bytes to p3d_comm_init. */
+#define P3D_COMM_ID_BYTES 128
+int p3d_comm_unique_id(void* id_out);
+int p3d_comm_init(p3d_handle* h, const void* id);
+
+/* ---- single operators on host arrays (the TF ops the path is made of), for op-level parity
+ *      tests.  SAME padding, NDHWC, filters [kd,kh,kw,Cin,Cout]; strides s[3] = (sd,sh,sw). */
+int p3d_op_conv3d(int device, const float* x, const int64_t xshape[5], const float* w, const int64_t wshape[5],
+                  const int s[3], const float* bias, float* y);                       /* tf.nn.conv3d (+bias_add) */
+int p3d_op_conv3d_backprop_input(int device, const float* dy, const float* w, const int64_t wshape[5],
+                                 const int s[3], const int64_t xshape[5], float* dx);
+int p3d_op_conv3d_backprop_filter(int device, const float* x, const int64_t xshape[5], const float* dy,
+                                  const int64_t wshape[5], const int s[3], float* dw, float* dbias);
+/* tf.layers.conv3d_transpose 'same'; kernel [kd,kh,kw,Cout,Cin] */
+int p3d_op_conv3d_transpose(int device, const float* x, const int64_t xshape[5], const float* k,
+                            const int64_t kshape[5], const int s[3], const float* bias, float* y);
+int p3d_op_max_pool3d(int device, const float* x, const int64_t xshape[5], const int ksize[3], const int s[3], float* y);
+int p3d_op_max_pool3d_grad(int device, const float* x, const int64_t xshape[5], const int ksize[3], const int s[3],
+                           const float* dy, float* dx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,470 @@
+// HBM-bound passes of the P3D path on gfx950: BatchNorm finalize / fused normalise+ReLU+add
+// passes and their backward, SAME max-pooling, Smooth-L1 loss, Adam.  All are float4-vectorised
+// over the channel axis of NDHWC rows (C % 4 == 0) with explicit row strides so they operate in
+// place on channel slices of the decoder's concat buffers (tf.concat at reference
+// p3d.py:203,208 never materialises).
+#include "p3d_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
+__device__ __forceinline__ float4 gate4(float4 g, float4 pre) {   // g where pre > 0 (tf.nn.relu gradient)
+    return make_float4(pre.x > 0.f ? g.x : 0.f, pre.y > 0.f ? g.y : 0.f, pre.z > 0.f ? g.z : 0.f, pre.w > 0.f ? g.w : 0.f);
+}
+
+// counter-based uniform in [0,1): splitmix64 finaliser of (seed, element index)
+__device__ __forceinline__ float u01(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float4 dropmask4(unsigned long long seed, long long e0, float rate, float scale) {
+    return make_float4(u01(seed, e0) >= rate ? scale : 0.f, u01(seed, e0 + 1) >= rate ? scale : 0.f,
+                       u01(seed, e0 + 2) >= rate ? scale : 0.f, u01(seed, e0 + 3) >= rate ? scale : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(BnParams bn, double invM, int use_batch, int update_moving, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= bn.C) return;
+    double mean, var;
+    if (use_batch) {
+        mean = bn.stats[2 * c] * invM;
+        var = bn.stats[2 * c + 1] * invM - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (update_moving) {      // moving -= (moving - batch) * (1 - 0.99)   (biased variance, Appendix A.4)
+            bn.moving_mean[c] -= (bn.moving_mean[c] - (float)mean) * (1.0f - 0.99f);
+            bn.moving_var[c] -= (bn.moving_var[c] - (float)var) * (1.0f - 0.99f);
+        }
+    } else {
+        mean = bn.moving_mean[c];
+        var = bn.moving_var[c];
+    }
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)bn.gamma[c] * inv);
+    bn.scale[c] = sc;
+    bn.shift[c] = (float)((double)bn.beta[c] - mean * (double)bn.gamma[c] * inv);
+    bn.mean[c] = (float)mean;
+    bn.invstd[c] = (float)inv;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
+    const int c4n = a.C >> 2;
+    const long long total = a.M * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / c4n;
+        const int c = (int)(i - row * c4n) << 2;
+        float4 v = fma4(ld4(a.scale1 + c), ld4(a.y1 + row * a.ld1 + c), ld4(a.shift1 + c));
+        float4 z;
+        if (MODE == 0) z = relu4(v);
+        else if (MODE == 1) z = relu4(add4(v, ld4(a.y2 + row * a.ld2 + c)));
+        else if (MODE == 2) z = relu4(add4(v, fma4(ld4(a.scale2 + c), ld4(a.y2 + row * a.ld2 + c), ld4(a.shift2 + c))));
+        else if (MODE == 3) z = add4(relu4(v), relu4(fma4(ld4(a.scale2 + c), ld4(a.y2 + row * a.ld2 + c), ld4(a.shift2 + c))));
+        else z = add4(ld4(a.y2 + row * a.ld2 + c), relu4(v));
+        if (a.drop_scale > 0.f) z = mul4(z, dropmask4(a.seed, row * a.C + c, a.drop_rate, a.drop_scale));
+        st4(a.z + row * a.ldz + c, z);
+    }
+}
+
+// gradient entering BN1 / BN2 (after the ReLU gates) for one float4 of one row
+template <int MODE>
+__device__ __forceinline__ void bn_bwd_gates(const BnBwdArgs& a, long long row, int c, float4& g1, float4& g2,
+                                             float4& y1, float4& y2) {
+    float4 dz = ld4(a.dz + row * a.lddz + c);
+    if (a.drop_scale > 0.f) dz = mul4(dz, dropmask4(a.seed, row * a.C + c, a.drop_rate, a.drop_scale));
+    y1 = ld4(a.y1 + row * a.ld1 + c);
+    const float4 v1 = fma4(ld4(a.scale1 + c), y1, ld4(a.shift1 + c));
+    y2 = f4(0.f);
+    if (MODE == 0) { g1 = gate4(dz, v1); g2 = f4(0.f); }
+    else if (MODE == 1) { y2 = ld4(a.y2 + row * a.ld2 + c); g1 = gate4(dz, add4(v1, y2)); g2 = g1; }
+    else if (MODE == 2) {
+        y2 = ld4(a.y2 + row * a.ld2 + c);
+        const float4 v2 = fma4(ld4(a.scale2 + c), y2, ld4(a.shift2 + c));
+        g1 = gate4(dz, add4(v1, v2)); g2 = g1;
+    } else if (MODE == 3) {
+        y2 = ld4(a.y2 + row * a.ld2 + c);
+        const float4 v2 = fma4(ld4(a.scale2 + c), y2, ld4(a.shift2 + c));
+        g1 = gate4(dz, v1); g2 = gate4(dz, v2);
+    } else { g1 = gate4(dz, v1); g2 = dz; }
+}
+
+// Per-channel sums of g and g*xhat.  Thread = one float4 channel group, RPI rows per block pass.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+    constexpr bool TWO = (MODE == 2 || MODE == 3);
+    __shared__ float red[256][TWO ? 16 : 8];
+    const int c4n = a.C >> 2;
+    const int rpi = 256 / c4n;                 // rows handled per block iteration (c4n <= 256)
+    const int tid = threadIdx.x;
+    const int sub = tid / c4n;
+    const int cg = tid - sub * c4n;
+    const int c = cg << 2;
+    const bool active = sub < rpi;
+    float4 s1 = f4(0.f), sx1 = f4(0.f), s2 = f4(0.f), sx2 = f4(0.f);
+    if (active) {
+        const float4 m1 = ld4(a.mean1 + c), i1 = ld4(a.invstd1 + c);
+        float4 m2 = f4(0.f), i2 = f4(0.f);
+        if (TWO) { m2 = ld4(a.mean2 + c); i2 = ld4(a.invstd2 + c); }
+        for (long long row = (long long)blockIdx.x * rpi + sub; row < a.M; row += (long long)gridDim.x * rpi) {
+            float4 g1, g2, y1, y2;
+            bn_bwd_gates<MODE>(a, row, c, g1, g2, y1, y2);
+            s1 = add4(s1, g1);
+            sx1 = fma4(g1, mul4(sub4(y1, m1), i1), sx1);
+            if (TWO) {
+                s2 = add4(s2, g2);
+                sx2 = fma4(g2, mul4(sub4(y2, m2), i2), sx2);
+            }
+        }
+    }
+    float* r = red[tid];
+    r[0] = s1.x; r[1] = s1.y; r[2] = s1.z; r[3] = s1.w; r[4] = sx1.x; r[5] = sx1.y; r[6] = sx1.z; r[7] = sx1.w;
+    if (TWO) { r[8] = s2.x; r[9] = s2.y; r[10] = s2.z; r[11] = s2.w; r[12] = sx2.x; r[13] = sx2.y; r[14] = sx2.z; r[15] = sx2.w; }
+    __syncthreads();
+    if (tid < c4n) {
+        constexpr int NV = TWO ? 16 : 8;
+        float t[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) t[q] = 0.f;
+        for (int s = 0; s < rpi; ++s)
+#pragma unroll
+            for (int q = 0; q < NV; ++q) t[q] += red[s * c4n + tid][q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsafeAtomicAdd(&a.red1[2 * (c + q) + 0], (double)t[q]);
+            unsafeAtomicAdd(&a.red1[2 * (c + q) + 1], (double)t[4 + q]);
+            if (TWO) {
+                unsafeAtomicAdd(&a.red2[2 * (c + q) + 0], (double)t[8 + q]);
+                unsafeAtomicAdd(&a.red2[2 * (c + q) + 1], (double)t[12 + q]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float4 ldred(const double* r, int c, int which, float scale) {
+    return make_float4((float)(r[2 * c + which] * scale), (float)(r[2 * (c + 1) + which] * scale),
+                       (float)(r[2 * (c + 2) + which] * scale), (float)(r[2 * (c + 3) + which] * scale));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+    constexpr bool TWO = (MODE == 2 || MODE == 3);
+    const int c4n = a.C >> 2;
+    const long long total = a.M * c4n;
+    const float invM = 1.0f / (float)a.M;
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // parameter gradients (each BN parameter is produced exactly once per step)
+    if (gtid < a.C) {
+        const int c = (int)gtid;
+        a.dbeta1[c] = (float)a.red1[2 * c];
+        a.dgamma1[c] = (float)a.red1[2 * c + 1];
+        if (TWO) { a.dbeta2[c] = (float)a.red2[2 * c]; a.dgamma2[c] = (float)a.red2[2 * c + 1]; }
+    }
+    for (long long i = gtid; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / c4n;
+        const int c = (int)(i - row * c4n) << 2;
+        float4 g1, g2, y1, y2;
+        bn_bwd_gates<MODE>(a, row, c, g1, g2, y1, y2);
+        {
+            const float4 k = mul4(ld4(a.gamma1 + c), ld4(a.invstd1 + c));
+            float4 d;
+            if (a.batch1) {
+                const float4 xh = mul4(sub4(y1, ld4(a.mean1 + c)), ld4(a.invstd1 + c));
+                const float4 c1 = ldred(a.red1, c, 0, invM), c2 = ldred(a.red1, c, 1, invM);
+                d = mul4(k, sub4(sub4(g1, c1), mul4(xh, c2)));
+            } else d = mul4(k, g1);
+            float* dst = a.dy1 + row * a.lddy1 + c;
+            if (a.acc1) d = add4(d, ld4(dst));
+            st4(dst, d);
+        }
+        if (MODE != 0) {
+            float4 d;
+            if (TWO) {
+                const float4 k = mul4(ld4(a.gamma2 + c), ld4(a.invstd2 + c));
+                if (a.batch2) {
+                    const float4 xh = mul4(sub4(y2, ld4(a.mean2 + c)), ld4(a.invstd2 + c));
+                    const float4 c1 = ldred(a.red2, c, 0, invM), c2 = ldred(a.red2, c, 1, invM);
+                    d = mul4(k, sub4(sub4(g2, c1), mul4(xh, c2)));
+                } else d = mul4(k, g2);
+            } else d = g2;            // residual branch (modes 1, 4)
+            float* dst = a.dy2 + row * a.lddy2 + c;
+            if (a.acc2) d = add4(d, ld4(dst));
+            st4(dst, d);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolArgs a) {
+    const int c4n = a.C >> 2;
+    const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long pos = i / c4n;
+        const int c = (int)(i - pos * c4n) << 2;
+        const long long opos = pos;
+        const int ow = (int)(pos % a.Wo); pos /= a.Wo;
+        const int oh = (int)(pos % a.Ho); pos /= a.Ho;
+        const int od = (int)(pos % a.Do); const int n = (int)(pos / a.Do);
+        float4 best = f4(-INFINITY);
+        for (int kd = 0; kd < a.kd; ++kd) {
+            const int id = od * a.sd - a.pd + kd;
+            if ((unsigned)id >= (unsigned)a.Di) continue;
+            for (int kh = 0; kh < a.kh; ++kh) {
+                const int ih = oh * a.sh - a.ph + kh;
+                if ((unsigned)ih >= (unsigned)a.Hi) continue;
+                for (int kw = 0; kw < a.kw; ++kw) {
+                    const int iw = ow * a.sw - a.pw + kw;
+                    if ((unsigned)iw >= (unsigned)a.Wi) continue;
+                    const float4 v = ld4(a.x + ((((long long)n * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.ldx + c);
+                    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
+                    best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+                }
+            }
+        }
+        st4(a.y + opos * a.ldy + c, best);
+    }
+}
+
+// dx[argmax] += dy, first maximum in (kd,kh,kw) scan order.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolArgs a) {
+    const int c4n = a.C >> 2;
+    const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long pos = i / c4n;
+        const int c = (int)(i - pos * c4n) << 2;
+        const long long opos = pos;
+        const int ow = (int)(pos % a.Wo); pos /= a.Wo;
+        const int oh = (int)(pos % a.Ho); pos /= a.Ho;
+        const int od = (int)(pos % a.Do); const int n = (int)(pos / a.Do);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        long long arg[4] = {-1, -1, -1, -1};
+        for (int kd = 0; kd < a.kd; ++kd) {
+            const int id = od * a.sd - a.pd + kd;
+            if ((unsigned)id >= (unsigned)a.Di) continue;
+            for (int kh = 0; kh < a.kh; ++kh) {
+                const int ih = oh * a.sh - a.ph + kh;
+                if ((unsigned)ih >= (unsigned)a.Hi) continue;
+                for (int kw = 0; kw < a.kw; ++kw) {
+                    const int iw = ow * a.sw - a.pw + kw;
+                    if ((unsigned)iw >= (unsigned)a.Wi) continue;
+                    const long long ipos = (((long long)n * a.Di + id) * a.Hi + ih) * a.Wi + iw;
+                    const float4 v = ld4(a.x + ipos * a.ldx + c);
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (vv[q] > best[q]) { best[q] = vv[q]; arg[q] = ipos; }
+                }
+            }
+        }
+        const float4 g = ld4(a.dy + opos * a.lddy + c);
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (arg[q] >= 0) unsafeAtomicAdd(a.dx + arg[q] * a.lddx + c + q, gg[q]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const float* pred, const float* target, long long n,
+                                                        double* loss_out, float* dl, int through_sigmoid) {
+    __shared__ double wsum[4];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float p = pred[i];
+        const float d = p - target[i];
+        const float ad = fabsf(d);
+        acc += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+        float g = ad < 1.f ? d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        if (through_sigmoid) g *= p * (1.f - p);
+        dl[i] = g;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss_out, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n4,
+                                                   long long n, float lr_t, float b1, float b2, float eps) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i << 2;
+        if (e + 3 < n) {
+            const float4 gg = ld4(g + e);
+            float4 mm = ld4(m + e), vv = ld4(v + e), pp = ld4(p + e);
+            const float gs[4] = {gg.x, gg.y, gg.z, gg.w};
+            float ms[4] = {mm.x, mm.y, mm.z, mm.w}, vs[4] = {vv.x, vv.y, vv.z, vv.w}, ps[4] = {pp.x, pp.y, pp.z, pp.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ms[q] = b1 * ms[q] + (1.f - b1) * gs[q];
+                vs[q] = b2 * vs[q] + (1.f - b2) * gs[q] * gs[q];
+                ps[q] -= lr_t * ms[q] / (sqrtf(vs[q]) + eps);
+            }
+            st4(m + e, make_float4(ms[0], ms[1], ms[2], ms[3]));
+            st4(v + e, make_float4(vs[0], vs[1], vs[2], vs[3]));
+            st4(p + e, make_float4(ps[0], ps[1], ps[2], ps[3]));
+        } else {
+            for (long long q = e; q < n; ++q) {
+                const float gq = g[q];
+                const float mq = b1 * m[q] + (1.f - b1) * gq;
+                const float vq = b2 * v[q] + (1.f - b2) * gq * gq;
+                m[q] = mq; v[q] = vq;
+                p[q] -= lr_t * mq / (sqrtf(vq) + eps);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* dst, int lddst, const float* src, int ldsrc, long long M, int C, int copy) {
+    const int c4n = C >> 2;
+    const long long total = M * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / c4n;
+        const int c = (int)(i - row * c4n) << 2;
+        float4 v = ld4(src + row * ldsrc + c);
+        if (!copy) v = add4(v, ld4(dst + row * lddst + c));
+        st4(dst + row * lddst + c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_uniform_kernel(float* p, long long n, float lo, float hi, unsigned long long seed) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p[i] = lo + (hi - lo) * u01(seed, (unsigned long long)i);
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* dy, int ld, long long M, int C, float* out) {
+    // thread = one channel; blocks stride over rows; one atomic per (block, channel)
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (long long row = blockIdx.x; row < M; row += gridDim.x) acc += dy[row * ld + c];
+    unsafeAtomicAdd(out + c, acc);
+}
+
+inline unsigned grid_for(long long total, int per_block = 256, int cap = 4096) {
+    long long b = (total + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+hipError_t p3d_bn_finalize(const BnParams& bn, long M, int use_batch, int update_moving, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((bn.C + 255) / 256), dim3(256), 0, s, bn, 1.0 / (double)M, use_batch,
+                       update_moving, eps);
+    return hipGetLastError();
+}
+
+hipError_t p3d_bn_apply(const BnApplyArgs& a, hipStream_t s) {
+    if ((a.C & 3) || (a.ld1 & 3) || (a.ldz & 3)) return hipErrorInvalidValue;
+    const unsigned g = grid_for(a.M * (a.C >> 2));
+    switch (a.mode) {
+        case 0: hipLaunchKernelGGL(bn_apply_kernel<0>, dim3(g), dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(g), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(bn_apply_kernel<2>, dim3(g), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(bn_apply_kernel<3>, dim3(g), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(g), dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
+    const int rpi = 256 / (a.C >> 2);
+    long long blocks = (a.M + (long long)rpi * 16 - 1) / ((long long)rpi * 16);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    const unsigned g = (unsigned)blocks;
+    switch (a.mode) {
+        case 0: hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, dim3(g), dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(g), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, dim3(g), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(bn_bwd_reduce_kernel<3>, dim3(g), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(g), dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t p3d_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s) {
+    if (a.C & 3) return hipErrorInvalidValue;
+    unsigned g = grid_for(a.M * (a.C >> 2));
+    if ((long long)g * 256 < a.C) g = (a.C + 255) / 256;
+    switch (a.mode) {
+        case 0: hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(g), dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(g), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, dim3(g), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(bn_bwd_apply_kernel<3>, dim3(g), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(g), dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t p3d_maxpool_fwd(const PoolArgs& a, hipStream_t s) {
+    if (a.C & 3) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * (a.C >> 2);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t p3d_maxpool_bwd(const PoolArgs& a, hipStream_t s) {
+    if (a.C & 3) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * (a.C >> 2);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t p3d_smooth_l1(const float* pred, const float* target, long n, double* loss_out, float* dlogits,
+                         int through_sigmoid, hipStream_t s) {
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, pred, target, (long long)n,
+                       loss_out, dlogits, through_sigmoid);
+    return hipGetLastError();
+}
+
+hipError_t p3d_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
+                    hipStream_t s) {
+    const long long n4 = ((long long)n + 3) / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4)), dim3(256), 0, s, p, g, m, v, n4, (long long)n, lr_t, b1, b2, eps);
+    return hipGetLastError();
+}
+
+hipError_t p3d_add_inplace(float* dst, int lddst, const float* src, int ldsrc, long M, int C, hipStream_t s) {
+    if (C & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for((long long)M * (C >> 2))), dim3(256), 0, s, dst, lddst, src, ldsrc,
+                       (long long)M, C, 0);
+    return hipGetLastError();
+}
+
+hipError_t p3d_copy_strided(float* dst, int lddst, const float* src, int ldsrc, long M, int C, hipStream_t s) {
+    if (C & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for((long long)M * (C >> 2))), dim3(256), 0, s, dst, lddst, src, ldsrc,
+                       (long long)M, C, 1);
+    return hipGetLastError();
+}
+
+hipError_t p3d_fill_uniform(float* p, long n, float lo, float hi, unsigned long long seed, hipStream_t s) {
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, (long long)n, lo, hi, seed);
+    return hipGetLastError();
+}
+
+hipError_t p3d_colsum(const float* dy, int ld, long M, int C, float* out, hipStream_t s) {
+    long long bx = (M + 63) / 64;
+    if (bx > 512) bx = 512;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)bx, (C + 255) / 256), dim3(256), 0, s, dy, ld, (long long)M, C, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,186 @@
+// Output head of p3d_unet on gfx950: tf.layers.conv3d_transpose(x, 1, 3, [2,2,2], 'same') followed by
+// tf.sigmoid (reference p3d.py:217-219), forward and both gradients.  Cout = 1 makes this an
+// HBM-bound stencil, not a GEMM, so it stays on the VALU: out[2i+k] += <x[i,:], K[k,0,:]> per axis
+// (k=3 s=2: pad_before 0, the element at 2*I is dropped).
+//
+// forward : one thread per INPUT lattice point g produces the 2x2x2 output cube at 2g+p; parity
+//           p=0 on an axis takes taps {0 from i=g, 2 from i=g-1}, p=1 takes tap 1 from i=g,
+//           so each thread reads the 8 neighbours g-{0,1}^3 once and does the 27 tap dots.
+// dgrad   : dx[g,c] = sum_k dlogits[2g+k] * K[k,0,c]   (27 taps, bounds-checked)
+// wgrad   : dK[k,0,c] = sum_g dlogits[2g+k] * x[g,c],  dbias = sum dlogits
+#include "p3d_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
+    extern __shared__ float kw[];     // [27][C]
+    const int C = a.C;
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) kw[i] = a.k[i];
+    __syncthreads();
+    const long long total = (long long)a.N * a.D * a.H * a.W;
+    const float bias = a.bias[0];
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        long long t = g;
+        const int w = (int)(t % a.W); t /= a.W;
+        const int h = (int)(t % a.H); t /= a.H;
+        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+        float out[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[q] = bias;
+        for (int dd = 0; dd < 2; ++dd) {
+            if (d - dd < 0) continue;
+            for (int dh = 0; dh < 2; ++dh) {
+                if (h - dh < 0) continue;
+                for (int dw = 0; dw < 2; ++dw) {
+                    if (w - dw < 0) continue;
+                    const float* xr = a.x + ((((long long)n * a.D + (d - dd)) * a.H + (h - dh)) * a.W + (w - dw)) * C;
+                    // taps reachable from this neighbour: per axis delta=0 -> (k=0,p=0),(k=1,p=1); delta=1 -> (k=2,p=0)
+                    const int nkd = dd ? 1 : 2, nkh = dh ? 1 : 2, nkw = dw ? 1 : 2;
+                    for (int c = 0; c < C; c += 4) {
+                        const float4 xv = ld4(xr + c);
+                        for (int a0 = 0; a0 < nkd; ++a0) {
+                            const int kd = dd ? 2 : a0, pd = dd ? 0 : a0;
+                            for (int a1 = 0; a1 < nkh; ++a1) {
+                                const int kh = dh ? 2 : a1, ph = dh ? 0 : a1;
+                                for (int a2 = 0; a2 < nkw; ++a2) {
+                                    const int kk = dw ? 2 : a2, pw = dw ? 0 : a2;
+                                    const float* kp = kw + ((kd * 3 + kh) * 3 + kk) * C + c;
+                                    out[(pd * 2 + ph) * 2 + pw] += xv.x * kp[0] + xv.y * kp[1] + xv.z * kp[2] + xv.w * kp[3];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const int Do = 2 * a.D, Ho = 2 * a.H, Wo = 2 * a.W;
+#pragma unroll
+        for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const long long o = (((long long)n * Do + 2 * d + pd) * Ho + 2 * h + ph) * Wo + 2 * w;
+                const float v0 = out[(pd * 2 + ph) * 2], v1 = out[(pd * 2 + ph) * 2 + 1];
+                *reinterpret_cast<float2*>(a.logits + o) = make_float2(v0, v1);
+                *reinterpret_cast<float2*>(a.pred + o) = make_float2(1.f / (1.f + __expf(-v0)), 1.f / (1.f + __expf(-v1)));
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_input_kernel(HeadArgs a) {
+    extern __shared__ float kw[];
+    const int C = a.C, c4n = C >> 2;
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) kw[i] = a.k[i];
+    __syncthreads();
+    const long long total = (long long)a.N * a.D * a.H * a.W * c4n;
+    const int Do = 2 * a.D, Ho = 2 * a.H, Wo = 2 * a.W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i / c4n;
+        const int c = (int)(i - t * c4n) << 2;
+        const long long g = t;
+        const int w = (int)(t % a.W); t /= a.W;
+        const int h = (int)(t % a.H); t /= a.H;
+        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int kd = 0; kd < 3; ++kd) {
+            const int od = 2 * d + kd;
+            if (od >= Do) continue;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int oh = 2 * h + kh;
+                if (oh >= Ho) continue;
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int ow = 2 * w + kk;
+                    if (ow >= Wo) continue;
+                    const float gdl = a.dlogits[(((long long)n * Do + od) * Ho + oh) * Wo + ow];
+                    const float* kp = kw + ((kd * 3 + kh) * 3 + kk) * C + c;
+                    acc.x += gdl * kp[0]; acc.y += gdl * kp[1]; acc.z += gdl * kp[2]; acc.w += gdl * kp[3];
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(a.dx + g * C + c) = acc;
+    }
+}
+
+// block: 256 threads = (256/C) position lanes x C channels; each thread keeps 27 tap accumulators.
+__global__ __launch_bounds__(256) void head_bwd_filter_kernel(HeadArgs a) {
+    __shared__ float red[256];
+    const int C = a.C;
+    const int lanes = 256 / C;
+    const int c = threadIdx.x % C, sub = threadIdx.x / C;
+    const long long total = (long long)a.N * a.D * a.H * a.W;
+    const int Do = 2 * a.D, Ho = 2 * a.H, Wo = 2 * a.W;
+    float acc[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = 0.f;
+    float bsum = 0.f;
+    if (sub < lanes) {
+        for (long long g = (long long)blockIdx.x * lanes + sub; g < total; g += (long long)gridDim.x * lanes) {
+            long long t = g;
+            const int w = (int)(t % a.W); t /= a.W;
+            const int h = (int)(t % a.H); t /= a.H;
+            const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+            const float xv = a.x[g * C + c];
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const int od = 2 * d + kd, oh = 2 * h + kh, ow = 2 * w + kk;
+                        float gdl = 0.f;
+                        if (od < Do && oh < Ho && ow < Wo) gdl = a.dlogits[(((long long)n * Do + od) * Ho + oh) * Wo + ow];
+                        acc[(kd * 3 + kh) * 3 + kk] += gdl * xv;
+                        if (c == 0 && kd < 2 && kh < 2 && kk < 2) bsum += gdl;   // each output counted once
+                    }
+        }
+    }
+    for (int q = 0; q < 27; ++q) {
+        red[threadIdx.x] = (sub < lanes) ? acc[q] : 0.f;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float s = 0.f;
+            for (int l = 0; l < lanes; ++l) s += red[l * C + threadIdx.x];
+            unsafeAtomicAdd(a.dk + q * C + threadIdx.x, s);
+        }
+        __syncthreads();
+    }
+    red[threadIdx.x] = (sub < lanes && c == 0) ? bsum : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int l = 0; l < lanes; ++l) s += red[l * C];
+        unsafeAtomicAdd(a.dbias, s);
+    }
+}
+
+}  // namespace
+
+hipError_t p3d_head_fwd(const HeadArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 256) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.D * a.H * a.W;
+    long long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)b), dim3(256), 27 * a.C * sizeof(float), s, a);
+    return hipGetLastError();
+}
+
+hipError_t p3d_head_bwd_input(const HeadArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 256) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.D * a.H * a.W * (a.C >> 2);
+    long long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(head_bwd_input_kernel, dim3((unsigned)b), dim3(256), 27 * a.C * sizeof(float), s, a);
+    return hipGetLastError();
+}
+
+hipError_t p3d_head_bwd_filter(const HeadArgs& a, hipStream_t s) {
+    if (a.C > 256 || a.C < 1) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.D * a.H * a.W;
+    const int lanes = 256 / a.C;
+    long long b = (total + (long long)lanes * 32 - 1) / ((long long)lanes * 32);
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(head_bwd_filter_kernel, dim3((unsigned)b), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

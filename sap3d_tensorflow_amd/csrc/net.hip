@@ -1,0 +1,1219 @@
+// Host runtime of libp3dhip: builds the P3D graph once (static shapes, everything resident in
+// HBM), then runs forward / backward / Adam as a fixed list of kernel launches on one HIP stream,
+// with RCCL gradient all-reduce on a side stream.  Graph structure follows the reference's
+// graph-building functions (p3d.py:10-221) but nothing else of TF's runtime is mirrored: there is
+// no session, no tracing, no host-resident variables.
+//
+// Parameters live in ONE flat fp32 buffer in creation (= forward) order with matching flat
+// gradient / Adam-moment buffers, so the optimiser is one kernel and gradient buckets for the
+// all-reduce are contiguous ranges that complete back-to-front during backward.
+#include "../../include/p3d_hip.h"
+#include "p3d_kernels.h"
+
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+struct P3dError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define HIPCHECK(expr)                                                                               \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            throw P3dError(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                           std::to_string(__LINE__) + ")");                                          \
+    } while (0)
+#define NCCLCHECK(expr)                                                                              \
+    do {                                                                                             \
+        ncclResult_t r_ = (expr);                                                                    \
+        if (r_ != ncclSuccess) throw P3dError(std::string(#expr) + " failed: " + ncclGetErrorString(r_)); \
+    } while (0)
+
+enum InitKind { INIT_XAVIER = 0, INIT_ZEROS = 1, INIT_ONES = 2 };
+
+struct Param {
+    std::string name;
+    std::vector<int64_t> shape;
+    int64_t count = 0, off = 0;
+    bool trainable = true;
+    int init = INIT_XAVIER;
+    float* p = nullptr;     // device
+    float* g = nullptr;     // device gradient (trainables)
+};
+
+struct Act {
+    std::string name;
+    int N = 0, D = 0, H = 0, W = 0, C = 0, ld = 0;
+    float* p = nullptr;
+    float* g = nullptr;
+    Act* parent = nullptr;          // channel-slice view of parent's storage
+    std::vector<Act*> views;
+    char* last_flag = nullptr;      // accumulate-flag of the most recently registered consumer
+    int64_t rows() const { return (int64_t)N * D * H * W; }
+};
+
+struct BN {
+    std::string name;
+    int C = 0;
+    Param *gamma = nullptr, *beta = nullptr, *mm = nullptr, *mv = nullptr;
+    int64_t stats_off = 0;          // into the stats arena (doubles)
+    float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;
+    bool follows_flag = false;      // obeys the `training` placeholder (stem / decoder); else always batch stats
+    bool used_batch = true;         // what the last forward used
+};
+
+struct Ctx {
+    bool training = false;
+    float drop = 0.f;
+    uint64_t seed = 0;
+    bool update_moving = false;
+    hipStream_t s = nullptr;
+};
+
+struct Op {
+    std::string name, kind;
+    double flops = 0, bytes = 0;            // forward algorithmic work
+    double bflops = 0, bbytes = 0;          // backward algorithmic work
+    int64_t first_param_off = -1;           // lowest flat offset of the params this op owns (-1: none)
+    std::function<void(const Ctx&)> fwd, bwd;
+};
+
+struct ConvGeo {       // a SAME forward conv: input extents -> output extents
+    int k[3], s[3], pad[3], I[3], O[3];
+};
+
+ConvGeo make_geo(int Di, int Hi, int Wi, const int k[3], const int s[3]) {
+    ConvGeo g;
+    const int in[3] = {Di, Hi, Wi};
+    for (int a = 0; a < 3; ++a) {
+        g.k[a] = k[a]; g.s[a] = s[a]; g.I[a] = in[a];
+        g.O[a] = (in[a] + s[a] - 1) / s[a];
+        int pt = (g.O[a] - 1) * s[a] + k[a] - in[a];
+        if (pt < 0) pt = 0;
+        g.pad[a] = pt / 2;
+    }
+    return g;
+}
+
+inline int pmod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
+
+// ---- launch-argument builders on the shared geometry ---------------------------------------------
+IgemmArgs igemm_conv_forward(const ConvGeo& g, int N, const float* x, int ldx, int Cin, float* y, int ldy, int Cout,
+                             const float* w, const float* bias, double* stats, int accum) {
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.N = N; a.Di = g.I[0]; a.Hi = g.I[1]; a.Wi = g.I[2]; a.ldx = ldx; a.K = Cin;
+    a.Gd = g.O[0]; a.Gh = g.O[1]; a.Gw = g.O[2];
+    a.isd = g.s[0]; a.ish = g.s[1]; a.isw = g.s[2];
+    a.y = y; a.Do = g.O[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.ldy = ldy; a.Nc = Cout;
+    a.osd = a.osh = a.osw = 1;
+    a.w = w; a.wT = 0; a.bias = bias; a.stats = stats; a.accum = accum;
+    int t = 0;
+    for (int kd = 0; kd < g.k[0]; ++kd)
+        for (int kh = 0; kh < g.k[1]; ++kh)
+            for (int kw = 0; kw < g.k[2]; ++kw) {
+                if (t >= P3D_MAX_TAPS) throw P3dError("kernel has too many taps");
+                a.taps[t].dd = (int16_t)(kd - g.pad[0]);
+                a.taps[t].dh = (int16_t)(kh - g.pad[1]);
+                a.taps[t].dw = (int16_t)(kw - g.pad[2]);
+                a.taps[t].widx = (int16_t)((kd * g.k[1] + kh) * g.k[2] + kw);
+                ++t;
+            }
+    a.ntaps = t;
+    return a;
+}
+
+// Input-gradient of the conv (== conv3d_transpose forward): one launch per residue class of the
+// conv-input lattice.  `dense` has the conv's OUTPUT extents, `out` the conv's INPUT extents.
+std::vector<IgemmArgs> igemm_conv_input_side(const ConvGeo& g, int N, const float* dense, int ld_dense, int Cdense,
+                                             float* out, int ld_out, int Cout_side, const float* w,
+                                             const float* bias, double* stats, int accum, bool include_empty) {
+    std::vector<IgemmArgs> v;
+    for (int pd = 0; pd < g.s[0]; ++pd)
+        for (int ph = 0; ph < g.s[1]; ++ph)
+            for (int pw = 0; pw < g.s[2]; ++pw) {
+                const int p[3] = {pd, ph, pw};
+                IgemmArgs a;
+                memset(&a, 0, sizeof(a));
+                bool empty_grid = false;
+                int G[3];
+                for (int ax = 0; ax < 3; ++ax) {
+                    G[ax] = (g.I[ax] - p[ax] + g.s[ax] - 1) / g.s[ax];
+                    if (g.I[ax] <= p[ax]) empty_grid = true;
+                }
+                if (empty_grid) continue;
+                a.x = dense; a.N = N; a.Di = g.O[0]; a.Hi = g.O[1]; a.Wi = g.O[2]; a.ldx = ld_dense; a.K = Cdense;
+                a.Gd = G[0]; a.Gh = G[1]; a.Gw = G[2];
+                a.isd = a.ish = a.isw = 1;
+                a.y = out; a.Do = g.I[0]; a.Ho = g.I[1]; a.Wo = g.I[2]; a.ldy = ld_out; a.Nc = Cout_side;
+                a.osd = g.s[0]; a.osh = g.s[1]; a.osw = g.s[2];
+                a.ood = pd; a.ooh = ph; a.oow = pw;
+                a.w = w; a.wT = 1; a.bias = bias; a.stats = stats; a.accum = accum;
+                int t = 0;
+                for (int kd = 0; kd < g.k[0]; ++kd) {
+                    if (pmod(pd + g.pad[0] - kd, g.s[0])) continue;
+                    for (int kh = 0; kh < g.k[1]; ++kh) {
+                        if (pmod(ph + g.pad[1] - kh, g.s[1])) continue;
+                        for (int kw = 0; kw < g.k[2]; ++kw) {
+                            if (pmod(pw + g.pad[2] - kw, g.s[2])) continue;
+                            if (t >= P3D_MAX_TAPS) throw P3dError("kernel has too many taps");
+                            // exact division (the residue is 0): floor semantics for negatives
+                            a.taps[t].dd = (int16_t)((pd + g.pad[0] - kd) / g.s[0]);
+                            a.taps[t].dh = (int16_t)((ph + g.pad[1] - kh) / g.s[1]);
+                            a.taps[t].dw = (int16_t)((pw + g.pad[2] - kw) / g.s[2]);
+                            a.taps[t].widx = (int16_t)((kd * g.k[1] + kh) * g.k[2] + kw);
+                            ++t;
+                        }
+                    }
+                }
+                a.ntaps = t;
+                if (t == 0 && !include_empty) continue;
+                v.push_back(a);
+            }
+    return v;
+}
+
+WgradArgs wgrad_conv(const ConvGeo& g, int N, const float* x, int ldx, int Cin, const float* dy, int ldy, int Cout,
+                     float* dw, float* dbias) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.N = N; a.Di = g.I[0]; a.Hi = g.I[1]; a.Wi = g.I[2]; a.ldx = ldx; a.K = Cin;
+    a.Gd = g.O[0]; a.Gh = g.O[1]; a.Gw = g.O[2];
+    a.isd = g.s[0]; a.ish = g.s[1]; a.isw = g.s[2];
+    a.dy = dy; a.ldy = ldy; a.Nc = Cout; a.dw = dw; a.dbias = dbias; a.ksplit = 1;
+    int t = 0;
+    for (int kd = 0; kd < g.k[0]; ++kd)
+        for (int kh = 0; kh < g.k[1]; ++kh)
+            for (int kw = 0; kw < g.k[2]; ++kw) {
+                if (t >= P3D_MAX_TAPS) throw P3dError("kernel has too many taps");
+                a.taps[t].dd = (int16_t)(kd - g.pad[0]);
+                a.taps[t].dh = (int16_t)(kh - g.pad[1]);
+                a.taps[t].dw = (int16_t)(kw - g.pad[2]);
+                a.taps[t].widx = (int16_t)((kd * g.k[1] + kh) * g.k[2] + kw);
+                ++t;
+            }
+    a.ntaps = t;
+    return a;
+}
+
+// firstconv1 (p3d.py:172): kd = 1, the kw x Cin run is contiguous in NDHWC, so a tap = kernel row kh.
+void stemify(const ConvGeo& g, int Cin, int& K, int& ntaps, P3dTap* taps, int& wfloats, int& wstep, int& wpad) {
+    if (g.k[0] != 1) throw P3dError("stem mode needs kd == 1");
+    K = g.k[2] * Cin;
+    ntaps = g.k[1];
+    for (int kh = 0; kh < g.k[1]; ++kh) {
+        taps[kh].dd = 0; taps[kh].dh = (int16_t)(kh - g.pad[1]); taps[kh].dw = 0; taps[kh].widx = (int16_t)kh;
+    }
+    wfloats = g.I[2] * Cin; wstep = g.s[2] * Cin; wpad = g.pad[2] * Cin;
+}
+
+void zero_strided(float* p, int ld, int64_t rows, int C, hipStream_t s) {
+    if (ld == C) HIPCHECK(hipMemsetAsync(p, 0, (size_t)rows * C * sizeof(float), s));
+    else HIPCHECK(hipMemset2DAsync(p, (size_t)ld * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)rows, s));
+}
+
+}  // namespace
+
+// ==================================================================================================
+struct p3d_handle {
+    p3d_config cfg;
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+    std::vector<void*> allocs;
+
+    std::deque<Param> params;                 // stable addresses
+    std::map<std::string, Param*> pindex;
+    std::vector<Param*> porder;               // creation order (trainables and states interleaved)
+    int64_t n_train = 0, n_state = 0;         // floats in the flat buffers
+    float *flat_p = nullptr, *flat_g = nullptr, *flat_m = nullptr, *flat_v = nullptr, *flat_state = nullptr;
+
+    std::deque<Act> acts;
+    std::map<std::string, Act*> named;
+    std::deque<BN> bns;
+    std::deque<char> flags;
+    std::map<std::string, int> uniq;
+
+    double* stats_arena = nullptr; int64_t stats_count = 0;
+    double* red_arena = nullptr;   int64_t red_count = 0;
+    float* bnbuf = nullptr;        int64_t bnbuf_count = 0;      // scale/shift/mean/invstd for every BN
+    std::vector<std::function<void()>> late_bind;                // pointer fix-ups after arenas are allocated
+
+    std::vector<Op> ops;
+    Act* x_in = nullptr;
+    Act* pred = nullptr;
+    Act* logits = nullptr;
+    float* d_y = nullptr;          // target
+    float* d_dlogits = nullptr;
+    double* d_loss = nullptr;
+    float lr = 1e-4f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    int64_t step = 0;
+
+    ncclComm_t comm = nullptr;
+    hipEvent_t ev_bucket = nullptr, ev_comm_done = nullptr;
+    int64_t bucket_floats = 8 << 20;          // 32 MB buckets
+
+    // ---------------------------------------------------------------------------------------------
+    template <typename T>
+    T* dalloc(int64_t n) {
+        void* p = nullptr;
+        if (n <= 0) n = 1;
+        HIPCHECK(hipMalloc(&p, (size_t)n * sizeof(T)));
+        allocs.push_back(p);
+        return (T*)p;
+    }
+
+    std::string unique(const std::string& base) {
+        int k = uniq[base]++;
+        return k == 0 ? base : base + "_" + std::to_string(k);
+    }
+
+    Param* add_param(const std::string& name, std::vector<int64_t> shape, bool trainable, int init) {
+        if (pindex.count(name)) throw P3dError("duplicate variable " + name);
+        params.emplace_back();
+        Param* p = &params.back();
+        p->name = name; p->shape = shape; p->trainable = trainable; p->init = init;
+        p->count = 1;
+        for (auto d : shape) p->count *= d;
+        int64_t& total = trainable ? n_train : n_state;
+        p->off = total;
+        total += (p->count + 63) / 64 * 64;          // 256-byte aligned slots
+        pindex[name] = p;
+        porder.push_back(p);
+        return p;
+    }
+
+    Act* new_act(const std::string& name, int N, int D, int H, int W, int C, bool with_grad = true) {
+        acts.emplace_back();
+        Act* a = &acts.back();
+        a->name = name; a->N = N; a->D = D; a->H = H; a->W = W; a->C = C; a->ld = C;
+        a->p = dalloc<float>(a->rows() * C);
+        if (with_grad) a->g = dalloc<float>(a->rows() * C);
+        if (!name.empty()) named[name] = a;
+        return a;
+    }
+    Act* new_view(Act* parent, int coff, int C, const std::string& name) {
+        acts.emplace_back();
+        Act* a = &acts.back();
+        *a = *parent;
+        a->name = name; a->C = C; a->parent = parent; a->views.clear(); a->last_flag = nullptr;
+        a->p = parent->p + coff;
+        a->g = parent->g ? parent->g + coff : nullptr;
+        parent->views.push_back(a);
+        if (!name.empty()) named[name] = a;
+        return a;
+    }
+
+    // Register a consumer of `a` whose backward adds into a->g.  Returns the flag the consumer reads
+    // at backward time: 0 = first writer (overwrite), 1 = accumulate.  Backward runs consumers in
+    // reverse registration order, so the newest registration is the writer.
+    char* consume(Act* a) {
+        flags.push_back(0);
+        char* f = &flags.back();
+        std::vector<Act*> region{a};
+        if (a->parent) region.push_back(a->parent);
+        for (Act* v : a->views) region.push_back(v);
+        for (Act* r : region) {
+            if (r->last_flag) *r->last_flag = 1;
+            r->last_flag = f;
+        }
+        return f;
+    }
+
+    BN* add_bn(const std::string& name_or_empty, int C, bool follows_flag) {
+        bns.emplace_back();
+        BN* bn = &bns.back();
+        bn->name = name_or_empty.empty() ? unique("batch_normalization") : name_or_empty;
+        bn->C = C; bn->follows_flag = follows_flag;
+        bn->gamma = add_param(bn->name + "/gamma", {C}, true, INIT_ONES);
+        bn->beta = add_param(bn->name + "/beta", {C}, true, INIT_ZEROS);
+        bn->mm = add_param(bn->name + "/moving_mean", {C}, false, INIT_ZEROS);
+        bn->mv = add_param(bn->name + "/moving_variance", {C}, false, INIT_ONES);
+        bn->stats_off = stats_count; stats_count += 2 * C;
+        const int64_t o = bnbuf_count; bnbuf_count += 4 * (int64_t)C;
+        late_bind.push_back([this, bn, o, C]() {
+            bn->scale = bnbuf + o; bn->shift = bnbuf + o + C; bn->mean = bnbuf + o + 2 * C; bn->invstd = bnbuf + o + 3 * C;
+        });
+        return bn;
+    }
+    double* bn_stats(BN* bn) { return stats_arena + bn->stats_off; }
+    BnParams bn_params(BN* bn) {
+        BnParams b;
+        b.gamma = bn->gamma->p; b.beta = bn->beta->p; b.moving_mean = bn->mm->p; b.moving_var = bn->mv->p;
+        b.stats = bn_stats(bn); b.scale = bn->scale; b.shift = bn->shift; b.mean = bn->mean; b.invstd = bn->invstd;
+        b.C = bn->C;
+        return b;
+    }
+
+    // ---- graph ops ---------------------------------------------------------------------------
+    // tf.nn.conv3d / tf.layers.conv3d: SAME conv, optional bias, optional BN-statistics epilogue.
+    Act* conv(const std::string& opname, Act* x, Param* w, Param* bias, const int k[3], const int s[3], int Cout, BN* bn,
+              const std::string& out_name, bool stem = false) {
+        const ConvGeo g = make_geo(x->D, x->H, x->W, k, s);
+        Act* y = new_act(out_name, x->N, g.O[0], g.O[1], g.O[2], Cout);
+        char* xflag = x->g ? consume(x) : nullptr;
+        const int Cin = x->C;
+        const int ntap = k[0] * k[1] * k[2];
+        Op op;
+        op.name = opname; op.kind = stem ? "conv_stem" : (ntap == 1 ? "conv_1x1x1" : "conv_kxkxk");
+        op.flops = 2.0 * y->rows() * ntap * Cin * Cout;
+        op.bytes = 4.0 * (x->rows() * (double)Cin + y->rows() * (double)Cout + (double)ntap * Cin * Cout);
+        op.bflops = op.flops * (x->g ? 2 : 1);
+        op.bbytes = op.bytes * (x->g ? 2 : 1);
+        op.first_param_off = w->off;
+        op.fwd = [=](const Ctx& c) {
+            IgemmArgs a = igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
+                                             bn ? bn_stats(bn) : nullptr, 0);
+            if (stem) stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
+            HIPCHECK(p3d_launch_igemm(a, c.s));
+        };
+        op.bwd = [=](const Ctx& c) {
+            WgradArgs wa = wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr);
+            if (stem) stemify(g, Cin, wa.K, wa.ntaps, wa.taps, wa.stem_wfloats, wa.stem_wstep, wa.stem_wpad);
+            HIPCHECK(p3d_launch_wgrad(wa, c.s));
+            if (xflag) {
+                const int accum = *xflag;
+                auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, w->p, nullptr, nullptr, accum,
+                                               /*include_empty=*/!accum);
+                for (auto& a : v) HIPCHECK(p3d_launch_igemm(a, c.s));
+            }
+        };
+        ops.push_back(op);
+        return y;
+    }
+
+    // tf.layers.conv3d_transpose(x, filters, k, s, 'same'): kernel [kd,kh,kw,Cout,Cin].
+    Act* deconv(const std::string& opname, Act* x, Param* kern, Param* bias, const int k[3], const int s[3], int Cout, BN* bn,
+                const std::string& out_name) {
+        const ConvGeo g = make_geo(x->D * s[0], x->H * s[1], x->W * s[2], k, s);    // conv whose input is y
+        Act* y = new_act(out_name, x->N, g.I[0], g.I[1], g.I[2], Cout);
+        char* xflag = x->g ? consume(x) : nullptr;
+        const int Cin = x->C;
+        Op op;
+        op.name = opname; op.kind = "deconv";
+        double taps_eff = 1;
+        for (int a = 0; a < 3; ++a) taps_eff *= (double)k[a] / s[a];
+        op.flops = 2.0 * y->rows() * taps_eff * Cin * Cout;
+        op.bytes = 4.0 * (x->rows() * (double)Cin + y->rows() * (double)Cout + (double)k[0] * k[1] * k[2] * Cin * Cout);
+        op.bflops = 2 * op.flops; op.bbytes = 2 * op.bytes;
+        op.first_param_off = kern->off;
+        op.fwd = [=](const Ctx& c) {
+            auto v = igemm_conv_input_side(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, kern->p, bias ? bias->p : nullptr,
+                                           bn ? bn_stats(bn) : nullptr, 0, true);
+            for (auto& a : v) HIPCHECK(p3d_launch_igemm(a, c.s));
+        };
+        op.bwd = [=](const Ctx& c) {
+            // dK[tap][co][ci] = sum dy_big[o][co] * x[i][ci]  (conv wgrad with the roles of x and dy swapped)
+            WgradArgs wa = wgrad_conv(g, x->N, y->g, y->ld, Cout, x->p, x->ld, Cin, kern->g, nullptr);
+            HIPCHECK(p3d_launch_wgrad(wa, c.s));
+            if (bias) HIPCHECK(p3d_colsum(y->g, y->ld, y->rows(), Cout, bias->g, c.s));
+            if (xflag) {
+                IgemmArgs a = igemm_conv_forward(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, kern->p, nullptr, nullptr, *xflag);
+                HIPCHECK(p3d_launch_igemm(a, c.s));
+            }
+        };
+        ops.push_back(op);
+        return y;
+    }
+
+    // BN finalize + fused normalise / ReLU / add pass (modes in p3d_kernels.h) and its backward.
+    Act* bn_apply(const std::string& opname, int mode, Act* y1, BN* bn1, Act* y2, BN* bn2, Act* out, const std::string& out_name,
+                  bool dropout = false) {
+        if (!out) out = new_act(out_name, y1->N, y1->D, y1->H, y1->W, y1->C);
+        else if (!out_name.empty()) named[out_name] = out;
+        consume(y1);                                 // y1 is a raw conv output: this op is its only consumer
+        char* f2 = nullptr;
+        if (y2) f2 = consume(y2);
+        const bool two = (mode == 2 || mode == 3);
+        const int64_t red_off = red_count;
+        red_count += (two ? 4 : 2) * (int64_t)y1->C;
+        const int64_t M = y1->rows();
+        const int C = y1->C;
+        Op op;
+        op.name = opname; op.kind = "bn_apply" + std::to_string(mode);
+        const double tens = (double)M * C * 4.0;
+        op.flops = 0; op.bytes = tens * (y2 ? 3 : 2);
+        op.bflops = 0; op.bbytes = tens * (y2 ? 7 : 5);
+        op.first_param_off = bn1->gamma->off;
+        if (two && bn2->gamma->off < op.first_param_off) op.first_param_off = bn2->gamma->off;
+        op.fwd = [=](const Ctx& c) {
+            auto fin = [&](BN* bn) {
+                bn->used_batch = bn->follows_flag ? c.training : true;
+                HIPCHECK(p3d_bn_finalize(bn_params(bn), M, bn->used_batch, bn->used_batch && c.update_moving, 1e-3f, c.s));
+            };
+            fin(bn1);
+            if (two) fin(bn2);
+            BnApplyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.mode = mode; a.M = M; a.C = C;
+            a.y1 = y1->p; a.ld1 = y1->ld; a.scale1 = bn1->scale; a.shift1 = bn1->shift;
+            if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; }
+            if (two) { a.scale2 = bn2->scale; a.shift2 = bn2->shift; }
+            a.z = out->p; a.ldz = out->ld;
+            if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
+            HIPCHECK(p3d_bn_apply(a, c.s));
+        };
+        op.bwd = [=](const Ctx& c) {
+            BnBwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.mode = mode; a.M = M; a.C = C;
+            a.dz = out->g; a.lddz = out->ld;
+            a.y1 = y1->p; a.ld1 = y1->ld; a.scale1 = bn1->scale; a.shift1 = bn1->shift; a.mean1 = bn1->mean; a.invstd1 = bn1->invstd;
+            a.gamma1 = bn1->gamma->p; a.dgamma1 = bn1->gamma->g; a.dbeta1 = bn1->beta->g; a.batch1 = bn1->used_batch;
+            a.red1 = red_arena + red_off;
+            a.dy1 = y1->g; a.lddy1 = y1->ld; a.acc1 = 0;
+            if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; a.dy2 = y2->g; a.lddy2 = y2->ld; a.acc2 = *f2; }
+            if (two) {
+                a.scale2 = bn2->scale; a.shift2 = bn2->shift; a.mean2 = bn2->mean; a.invstd2 = bn2->invstd;
+                a.gamma2 = bn2->gamma->p; a.dgamma2 = bn2->gamma->g; a.dbeta2 = bn2->beta->g; a.batch2 = bn2->used_batch;
+                a.red2 = red_arena + red_off + 2 * C;
+            }
+            if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
+            HIPCHECK(p3d_bn_bwd_reduce(a, c.s));
+            HIPCHECK(p3d_bn_bwd_apply(a, c.s));
+        };
+        ops.push_back(op);
+        return out;
+    }
+
+    // tf.nn.max_pool3d SAME
+    Act* maxpool(const std::string& opname, Act* x, const int k[3], const int s[3], Act* out, const std::string& out_name) {
+        const ConvGeo g = make_geo(x->D, x->H, x->W, k, s);
+        if (!out) out = new_act(out_name, x->N, g.O[0], g.O[1], g.O[2], x->C);
+        else if (!out_name.empty()) named[out_name] = out;
+        char* xflag = consume(x);
+        Op op;
+        op.name = opname; op.kind = "maxpool";
+        op.bytes = 4.0 * (x->rows() + out->rows()) * x->C;
+        op.bbytes = 4.0 * (2.0 * x->rows() + 2.0 * out->rows()) * x->C;
+        auto mk = [=]() {
+            PoolArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = x->p; a.N = x->N; a.Di = x->D; a.Hi = x->H; a.Wi = x->W; a.C = x->C; a.ldx = x->ld;
+            a.y = out->p; a.Do = g.O[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.ldy = out->ld;
+            a.kd = k[0]; a.kh = k[1]; a.kw = k[2]; a.sd = s[0]; a.sh = s[1]; a.sw = s[2];
+            a.pd = g.pad[0]; a.ph = g.pad[1]; a.pw = g.pad[2];
+            a.dy = out->g; a.lddy = out->ld; a.dx = x->g; a.lddx = x->ld;
+            return a;
+        };
+        op.fwd = [=](const Ctx& c) { HIPCHECK(p3d_maxpool_fwd(mk(), c.s)); };
+        op.bwd = [=](const Ctx& c) {
+            if (!*xflag) zero_strided(x->g, x->ld, x->rows(), x->C, c.s);
+            HIPCHECK(p3d_maxpool_bwd(mk(), c.s));
+        };
+        ops.push_back(op);
+        return out;
+    }
+
+    // ---- the reference graph -------------------------------------------------------------------
+    Param* conv_weight(const std::string& name, std::vector<int64_t> shape) { return add_param(name, shape, true, INIT_XAVIER); }
+
+    // Bottleneck.infer, p3d.py:83-136 (3-D branch only; the 2-D branch is unreachable)
+    Act* bottleneck(Act* x, int id, int inplanes, int planes, bool first, bool stride2) {
+        const std::string sid = std::to_string(id);
+        const char st = "ABC"[id % 3];
+        const int one[3] = {1, 1, 1};
+        const int s2[3] = {1, 2, 2};
+        const int* s = (first && stride2) ? s2 : one;
+        const int kS[3] = {1, 3, 3}, kT[3] = {3, 1, 1};
+        const std::string B = "block" + sid + "/";
+        // variable creation order matters for BN auto-naming
+        Param* w1 = conv_weight("conv3_" + sid + "_1", {1, 1, 1, inplanes, planes});
+        BN* bn1 = add_bn("", planes, false);
+        Act* y1 = conv(B + "conv1", x, w1, nullptr, one, s, planes, bn1, "");
+        Act* z1 = bn_apply(B + "bn1", 0, y1, bn1, nullptr, nullptr, nullptr, B + "conv1_bn_relu");
+        const std::string nm = std::string("ST") + st + "_" + sid + "_2";
+        Act* stout = nullptr;
+        if (st == 'A') {          // p3d.py:56-63
+            Param* wS = conv_weight(nm + "_S", {1, 3, 3, planes, planes});
+            Param* bS = conv_weight(nm + "_S_bias", {planes});
+            BN* bnS = add_bn("", planes, false);
+            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "");
+            Act* zS = bn_apply(B + "bnS", 0, yS, bnS, nullptr, nullptr, nullptr, "");
+            Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
+            Param* bT = conv_weight(nm + "_T_bias", {planes});
+            BN* bnT = add_bn("", planes, false);
+            Act* yT = conv(B + "convT", zS, wT, bT, kT, one, planes, bnT, "");
+            stout = bn_apply(B + "bnT", 0, yT, bnT, nullptr, nullptr, nullptr, B + "st");
+        } else if (st == 'B') {   // p3d.py:65-72
+            Param* wS = conv_weight(nm + "_S", {1, 3, 3, planes, planes});
+            Param* bS = conv_weight(nm + "_S_bias", {planes});
+            BN* bnS = add_bn("", planes, false);
+            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "");
+            Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
+            Param* bT = conv_weight(nm + "_T_bias", {planes});
+            BN* bnT = add_bn("", planes, false);
+            Act* yT = conv(B + "convT", z1, wT, bT, kT, one, planes, bnT, "");
+            stout = bn_apply(B + "bnST", 3, yS, bnS, yT, bnT, nullptr, B + "st");
+        } else {                  // p3d.py:74-81
+            Param* wS = conv_weight(nm + "_S", {1, 3, 3, planes, planes});
+            Param* bS = conv_weight(nm + "_S_bias", {planes});
+            BN* bnS = add_bn("", planes, false);
+            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "");
+            Act* zS = bn_apply(B + "bnS", 0, yS, bnS, nullptr, nullptr, nullptr, "");
+            Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
+            Param* bT = conv_weight(nm + "_T_bias", {planes});
+            BN* bnT = add_bn("", planes, false);
+            Act* yT = conv(B + "convT", zS, wT, bT, kT, one, planes, bnT, "");
+            stout = bn_apply(B + "bnT", 4, yT, bnT, zS, nullptr, nullptr, B + "st");
+        }
+        Param* w3 = conv_weight("conv3_" + sid + "_3", {1, 1, 1, planes, planes * 4});
+        BN* bn3 = add_bn("", planes * 4, false);
+        Act* y3 = conv(B + "conv3", stout, w3, nullptr, one, one, planes * 4, bn3, "");
+        if (first) {              // p3d.py:124-127
+            Param* wp = conv_weight("dw3d_" + sid, {1, 1, 1, inplanes, planes * 4});
+            BN* bnp = add_bn("", planes * 4, false);
+            Act* yp = conv(B + "proj", x, wp, nullptr, one, s, planes * 4, bnp, "");
+            return bn_apply(B + "bn3", 2, y3, bn3, yp, bnp, nullptr, B + "out");
+        }
+        return bn_apply(B + "bn3", 1, y3, bn3, x, nullptr, nullptr, B + "out");
+    }
+
+    void build_unet() {
+        const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
+        if (T % 16 || H % 16 || W % 16) throw P3dError("frames/height/width must be multiples of 16");
+        if (b % 8) throw P3dError("base must be a multiple of 8");
+        x_in = new_act("x", B, T, H, W, 3, /*with_grad=*/false);
+        // p3d.py:172-177
+        const int k177[3] = {1, 7, 7}, s122[3] = {1, 2, 2};
+        Param* w0 = conv_weight("firstconv1", {1, 7, 7, 3, b});
+        BN* bn0 = add_bn("", b, true);
+        Act* c1 = conv("stem/conv", x_in, w0, nullptr, k177, s122, b, bn0, "conv1_custom", /*stem=*/true);
+        Act* a1 = bn_apply("stem/bn", 0, c1, bn0, nullptr, nullptr, nullptr, "conv1_custom_bn_relu");
+        const int k233[3] = {2, 3, 3}, s222[3] = {2, 2, 2}, k211[3] = {2, 1, 1}, s211[3] = {2, 1, 1};
+        Act* cur = maxpool("pool1", a1, k233, s222, nullptr, "pool1");
+        // concat buffers of the decoder (p3d.py:203,208): [deconvN_re | poolM]
+        Act* cat1 = new_act("deconv1_concat", B, T / 8, H / 8, W / 8, 16 * b);
+        Act* cat2 = new_act("deconv2_concat", B, T / 4, H / 4, W / 4, 8 * b);
+        Act* pool2 = new_view(cat2, 4 * b, 4 * b, "pool2");
+        Act* pool3 = new_view(cat1, 8 * b, 8 * b, "pool3");
+        int id = 0, inpl = b;
+        const int planes[3] = {b, 2 * b, 4 * b};
+        Act* skips[3] = {pool2, pool3, nullptr};
+        const char* pool_names[3] = {"pool2", "pool3", "pool4"};
+        for (int stage = 0; stage < 3; ++stage) {
+            for (int j = 0; j < cfg.blocks[stage]; ++j) {
+                cur = bottleneck(cur, id, inpl, planes[stage], j == 0, stage > 0);
+                inpl = planes[stage] * 4;
+                ++id;
+            }
+            cur = maxpool(pool_names[stage], cur, k211, s211, skips[stage], pool_names[stage]);
+        }
+        Act* pool4 = cur;
+        // decoder p3d.py:200-219
+        const int k133[3] = {1, 3, 3}, k333[3] = {3, 3, 3}, k111[3] = {1, 1, 1}, s111[3] = {1, 1, 1};
+        {
+            Param* k = conv_weight("conv3d_transpose/kernel", {1, 3, 3, 8 * b, 16 * b});
+            Param* bi = add_param("conv3d_transpose/bias", {8 * b}, true, INIT_ZEROS);
+            BN* bn = add_bn("deconv1_bn", 8 * b, true);
+            Act* y = deconv("deconv1", pool4, k, bi, k133, s222, 8 * b, bn, "");
+            bn_apply("deconv1_bn", 0, y, bn, nullptr, nullptr, new_view(cat1, 0, 8 * b, "deconv1_re"), "");
+        }
+        {
+            Param* k = conv_weight("conv3d_transpose_1/kernel", {2, 3, 3, 4 * b, 16 * b});
+            Param* bi = add_param("conv3d_transpose_1/bias", {4 * b}, true, INIT_ZEROS);
+            BN* bn = add_bn("deconv2_bn", 4 * b, true);
+            Act* y = deconv("deconv2", cat1, k, bi, k233, s222, 4 * b, bn, "");
+            bn_apply("deconv2_bn", 0, y, bn, nullptr, nullptr, new_view(cat2, 0, 4 * b, "deconv2_re"), "");
+        }
+        Act* d3;
+        {
+            Param* k = conv_weight("conv3d_transpose_2/kernel", {3, 3, 3, 2 * b, 8 * b});
+            Param* bi = add_param("conv3d_transpose_2/bias", {2 * b}, true, INIT_ZEROS);
+            BN* bn = add_bn("deconv3_bn", 2 * b, true);
+            Act* y = deconv("deconv3", cat2, k, bi, k333, s222, 2 * b, bn, "");
+            d3 = bn_apply("deconv3_bn", 0, y, bn, nullptr, nullptr, nullptr, "deconv3_re", /*dropout=*/true);
+        }
+        Param* k4 = conv_weight("conv3d/kernel", {1, 1, 1, 2 * b, b / 2});
+        Param* b4 = add_param("conv3d/bias", {b / 2}, true, INIT_ZEROS);
+        Act* c4 = conv("deconv4_conv1", d3, k4, b4, k111, s111, b / 2, nullptr, "deconv4_conv1");
+        Param* k5 = conv_weight("conv3d_transpose_3/kernel", {3, 3, 3, 1, b / 2});
+        Param* b5 = add_param("conv3d_transpose_3/bias", {1}, true, INIT_ZEROS);
+        head(c4, k5, b5);
+    }
+
+    // results = sigmoid(conv3d_transpose(x, 1, 3, 2)) (p3d.py:217-219) + Smooth-L1 (train.py:156-159)
+    void head(Act* x, Param* k, Param* bias) {
+        logits = new_act("logits", x->N, 2 * x->D, 2 * x->H, 2 * x->W, 1, false);
+        pred = new_act("pred", x->N, 2 * x->D, 2 * x->H, 2 * x->W, 1, false);
+        d_dlogits = dalloc<float>(pred->rows());
+        d_y = dalloc<float>(pred->rows());
+        d_loss = dalloc<double>(1);
+        char* xflag = consume(x);
+        Op op;
+        op.name = "results"; op.kind = "head_deconv";
+        op.flops = 2.0 * x->rows() * 27 * x->C;
+        op.bytes = 4.0 * (x->rows() * (double)x->C + 2.0 * pred->rows());
+        op.bflops = 2 * op.flops; op.bbytes = 4.0 * (3.0 * x->rows() * (double)x->C + 2.0 * pred->rows());
+        op.first_param_off = k->off;
+        auto mk = [=]() {
+            HeadArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = x->p; a.N = x->N; a.D = x->D; a.H = x->H; a.W = x->W; a.C = x->C;
+            a.k = k->p; a.bias = bias->p; a.logits = logits->p; a.pred = pred->p;
+            a.dlogits = d_dlogits; a.dx = x->g; a.dk = k->g; a.dbias = bias->g;
+            return a;
+        };
+        op.fwd = [=](const Ctx& c) { HIPCHECK(p3d_head_fwd(mk(), c.s)); };
+        op.bwd = [=](const Ctx& c) {
+            if (*xflag) throw P3dError("head input gradient must be the first writer");
+            HIPCHECK(p3d_head_bwd_filter(mk(), c.s));
+            HIPCHECK(p3d_head_bwd_input(mk(), c.s));
+        };
+        ops.push_back(op);
+    }
+
+    void finalize_build() {
+        flat_p = dalloc<float>(n_train); flat_g = dalloc<float>(n_train);
+        flat_m = dalloc<float>(n_train); flat_v = dalloc<float>(n_train);
+        flat_state = dalloc<float>(n_state);
+        HIPCHECK(hipMemset(flat_p, 0, (size_t)n_train * 4)); HIPCHECK(hipMemset(flat_g, 0, (size_t)n_train * 4));
+        HIPCHECK(hipMemset(flat_m, 0, (size_t)n_train * 4)); HIPCHECK(hipMemset(flat_v, 0, (size_t)n_train * 4));
+        HIPCHECK(hipMemset(flat_state, 0, (size_t)n_state * 4));
+        for (Param* p : porder) {
+            if (p->trainable) { p->p = flat_p + p->off; p->g = flat_g + p->off; }
+            else p->p = flat_state + p->off;
+        }
+        stats_arena = dalloc<double>(stats_count);
+        red_arena = dalloc<double>(red_count);
+        bnbuf = dalloc<float>(bnbuf_count);
+        for (auto& f : late_bind) f();
+        late_bind.clear();
+    }
+
+    // ---- execution -------------------------------------------------------------------------------
+    void run_forward(const Ctx& c) {
+        HIPCHECK(hipMemsetAsync(stats_arena, 0, (size_t)stats_count * sizeof(double), c.s));
+        for (auto& op : ops) op.fwd(c);
+    }
+    void run_loss(const Ctx& c) {
+        HIPCHECK(hipMemsetAsync(d_loss, 0, sizeof(double), c.s));
+        HIPCHECK(p3d_smooth_l1(pred->p, d_y, pred->rows(), d_loss, d_dlogits, 1, c.s));
+    }
+    void run_backward(const Ctx& c, bool allreduce) {
+        HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
+        HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), c.s));
+        int64_t hi = n_train;                        // grads in [hi, n_train) are already handed to the comm stream
+        for (int i = (int)ops.size() - 1; i >= 0; --i) {
+            ops[i].bwd(c);
+            if (allreduce && comm && ops[i].first_param_off >= 0) {
+                // every parameter at offset >= first_param_off of op i is final now (creation order = forward order)
+                const int64_t lo = ops[i].first_param_off;
+                if (hi - lo >= bucket_floats || i == 0) {
+                    const int64_t start = (i == 0) ? 0 : lo;
+                    if (hi > start) reduce_range(start, hi, c.s);
+                    hi = start;
+                }
+            }
+        }
+        if (allreduce && comm) {
+            if (hi > 0) reduce_range(0, hi, c.s);
+            HIPCHECK(hipEventRecord(ev_comm_done, comm_stream));
+            HIPCHECK(hipStreamWaitEvent(c.s, ev_comm_done, 0));
+        }
+    }
+    void reduce_range(int64_t lo, int64_t hi, hipStream_t s) {
+        HIPCHECK(hipEventRecord(ev_bucket, s));
+        HIPCHECK(hipStreamWaitEvent(comm_stream, ev_bucket, 0));
+        NCCLCHECK(ncclAllReduce(flat_g + lo, flat_g + lo, (size_t)(hi - lo), ncclFloat, ncclSum, comm, comm_stream));
+    }
+    void run_adam(const Ctx& c) {
+        ++step;
+        const double t = (double)step;
+        const float lr_t = (float)(lr * std::sqrt(1.0 - std::pow((double)b2, t)) / (1.0 - std::pow((double)b1, t)));
+        HIPCHECK(p3d_adam(flat_p, flat_g, flat_m, flat_v, n_train, lr_t, b1, b2, eps, c.s));
+    }
+
+    void upload(const float* x, const float* y) {
+        if (x) HIPCHECK(hipMemcpyAsync(x_in->p, x, (size_t)x_in->rows() * 3 * sizeof(float), hipMemcpyHostToDevice, stream));
+        if (y) HIPCHECK(hipMemcpyAsync(d_y, y, (size_t)pred->rows() * sizeof(float), hipMemcpyHostToDevice, stream));
+    }
+    float read_loss() {
+        double l = 0;
+        HIPCHECK(hipMemcpyAsync(&l, d_loss, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+        return (float)l;
+    }
+    void download_act(Act* a, float* host) {
+        if (a->ld == a->C)
+            HIPCHECK(hipMemcpyAsync(host, a->p, (size_t)a->rows() * a->C * sizeof(float), hipMemcpyDeviceToHost, stream));
+        else
+            HIPCHECK(hipMemcpy2DAsync(host, (size_t)a->C * 4, a->p, (size_t)a->ld * 4, (size_t)a->C * 4, (size_t)a->rows(),
+                                      hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+    }
+
+    ~p3d_handle() {
+        if (comm) ncclCommDestroy(comm);
+        if (ev_bucket) hipEventDestroy(ev_bucket);
+        if (ev_comm_done) hipEventDestroy(ev_comm_done);
+        for (void* p : allocs) hipFree(p);
+        if (comm_stream) hipStreamDestroy(comm_stream);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+
+// ==================================================================================================
+#define API_BEGIN try {
+#define API_END                                        \
+    }                                                  \
+    catch (const std::exception& e) {                  \
+        g_err = e.what();                              \
+        return -1;                                     \
+    }                                                  \
+    return 0;
+
+extern "C" {
+
+const char* p3d_last_error(void) { return g_err.c_str(); }
+
+void p3d_default_config(p3d_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->structure = P3D_STRUCTURE_UNET;
+    c->batch = 2; c->frames = 16; c->height = 112; c->width = 112; c->base = 64;
+    c->blocks[0] = 3; c->blocks[1] = 8; c->blocks[2] = 36;
+    c->device = 0; c->world_size = 1; c->rank = 0;
+}
+
+int p3d_create(const p3d_config* cfg, p3d_handle** out) {
+    p3d_handle* h = nullptr;
+    try {
+        if (!cfg || !out) throw P3dError("null argument");
+        int ndev = 0;
+        HIPCHECK(hipGetDeviceCount(&ndev));
+        if (ndev <= 0) throw P3dError("no HIP device: libp3dhip has no CPU fallback");
+        if (cfg->device < 0 || cfg->device >= ndev) throw P3dError("bad device ordinal");
+        HIPCHECK(hipSetDevice(cfg->device));
+        h = new p3d_handle();
+        h->cfg = *cfg;
+        HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&h->ev_comm_done, hipEventDisableTiming));
+        if (cfg->structure != P3D_STRUCTURE_UNET) throw P3dError("unknown structure");
+        if (cfg->batch < 1) throw P3dError("batch must be >= 1");
+        for (int i = 0; i < 3; ++i)
+            if (cfg->blocks[i] < 1) throw P3dError("blocks must be >= 1");
+        h->build_unet();
+        h->finalize_build();
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        *out = h;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        delete h;
+        return -1;
+    }
+    return 0;
+}
+
+void p3d_destroy(p3d_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    delete h;
+}
+
+int p3d_num_params(p3d_handle* h) { return h ? (int)h->porder.size() : -1; }
+
+int p3d_param_info(p3d_handle* h, int index, const char** name, int* ndim, int64_t shape[5], int* trainable) {
+    API_BEGIN
+    if (!h || index < 0 || index >= (int)h->porder.size()) throw P3dError("bad parameter index");
+    Param* p = h->porder[index];
+    if (name) *name = p->name.c_str();
+    if (ndim) *ndim = (int)p->shape.size();
+    if (shape)
+        for (size_t i = 0; i < 5; ++i) shape[i] = i < p->shape.size() ? p->shape[i] : 1;
+    if (trainable) *trainable = p->trainable;
+    API_END
+}
+
+static Param* find_param(p3d_handle* h, const char* name, int64_t count) {
+    if (!h || !name) throw P3dError("null argument");
+    auto it = h->pindex.find(name);
+    if (it == h->pindex.end()) throw P3dError(std::string("no variable named ") + name);
+    if (count != it->second->count)
+        throw P3dError(std::string("size mismatch for ") + name + ": got " + std::to_string(count) + ", variable has " +
+                       std::to_string(it->second->count));
+    return it->second;
+}
+
+int p3d_set_param(p3d_handle* h, const char* name, const float* host, int64_t count) {
+    API_BEGIN
+    Param* p = find_param(h, name, count);
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    HIPCHECK(hipMemcpy(p->p, host, (size_t)count * 4, hipMemcpyHostToDevice));
+    API_END
+}
+int p3d_get_param(p3d_handle* h, const char* name, float* host, int64_t count) {
+    API_BEGIN
+    Param* p = find_param(h, name, count);
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipMemcpy(host, p->p, (size_t)count * 4, hipMemcpyDeviceToHost));
+    API_END
+}
+int p3d_get_grad(p3d_handle* h, const char* name, float* host, int64_t count) {
+    API_BEGIN
+    Param* p = find_param(h, name, count);
+    if (!p->trainable) throw P3dError(std::string(name) + " is not trainable");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipMemcpy(host, p->g, (size_t)count * 4, hipMemcpyDeviceToHost));
+    API_END
+}
+
+int p3d_init_params(p3d_handle* h, uint64_t seed) {
+    API_BEGIN
+    if (!h) throw P3dError("null handle");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    uint64_t idx = 0;
+    for (Param* p : h->porder) {
+        ++idx;
+        if (p->init == INIT_XAVIER) {
+            // tf.contrib.layers.xavier_initializer: U(-L, L), L = sqrt(6 / (fan_in + fan_out)); rank-1 [C]: fans = C
+            double fi, fo;
+            if (p->shape.size() == 1) fi = fo = (double)p->shape[0];
+            else {
+                double rf = 1;
+                for (size_t i = 0; i + 2 < p->shape.size(); ++i) rf *= (double)p->shape[i];
+                fi = rf * p->shape[p->shape.size() - 2];
+                fo = rf * p->shape[p->shape.size() - 1];
+            }
+            const float L = (float)std::sqrt(6.0 / (fi + fo));
+            HIPCHECK(p3d_fill_uniform(p->p, p->count, -L, L, seed * 0x9E3779B97F4A7C15ull + idx, h->stream));
+        } else {
+            const float v = p->init == INIT_ONES ? 1.f : 0.f;
+            HIPCHECK(p3d_fill_uniform(p->p, p->count, v, v, 0, h->stream));
+        }
+    }
+    HIPCHECK(hipMemsetAsync(h->flat_m, 0, (size_t)h->n_train * 4, h->stream));
+    HIPCHECK(hipMemsetAsync(h->flat_v, 0, (size_t)h->n_train * 4, h->stream));
+    h->step = 0;
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    API_END
+}
+
+int p3d_upload_inputs(p3d_handle* h, const float* x, const float* y) {
+    API_BEGIN
+    if (!h) throw P3dError("null handle");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    h->upload(x, y);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    API_END
+}
+
+int p3d_forward_device(p3d_handle* h, int training, float dropout_rate, uint64_t seed) {
+    API_BEGIN
+    if (!h) throw P3dError("null handle");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    Ctx c; c.training = training != 0; c.drop = dropout_rate; c.seed = seed; c.update_moving = false; c.s = h->stream;
+    h->run_forward(c);
+    API_END
+}
+
+int p3d_forward(p3d_handle* h, const float* x, int training, float dropout_rate, uint64_t seed, float* pred) {
+    API_BEGIN
+    if (!h || !x || !pred) throw P3dError("null argument");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    h->upload(x, nullptr);
+    Ctx c; c.training = training != 0; c.drop = dropout_rate; c.seed = seed; c.update_moving = false; c.s = h->stream;
+    h->run_forward(c);
+    h->download_act(h->pred, pred);
+    API_END
+}
+
+int p3d_backward(p3d_handle* h, const float* x, const float* y, float dropout_rate, uint64_t seed, float* loss, float* pred) {
+    API_BEGIN
+    if (!h || !x || !y) throw P3dError("null argument");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    h->upload(x, y);
+    Ctx c; c.training = true; c.drop = dropout_rate; c.seed = seed; c.update_moving = false; c.s = h->stream;
+    h->run_forward(c);
+    h->run_loss(c);
+    h->run_backward(c, false);
+    const float l = h->read_loss();
+    if (loss) *loss = l;
+    if (pred) h->download_act(h->pred, pred);
+    API_END
+}
+
+int p3d_train_step_device(p3d_handle* h, float dropout_rate, uint64_t seed) {
+    API_BEGIN
+    if (!h) throw P3dError("null handle");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    Ctx c; c.training = true; c.drop = dropout_rate; c.seed = seed; c.update_moving = true; c.s = h->stream;
+    h->run_forward(c);
+    h->run_loss(c);
+    h->run_backward(c, true);
+    h->run_adam(c);
+    API_END
+}
+
+int p3d_train_step(p3d_handle* h, const float* x, const float* y, float dropout_rate, uint64_t seed, float* loss) {
+    API_BEGIN
+    if (!h || !x || !y) throw P3dError("null argument");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    h->upload(x, y);
+    Ctx c; c.training = true; c.drop = dropout_rate; c.seed = seed; c.update_moving = true; c.s = h->stream;
+    h->run_forward(c);
+    h->run_loss(c);
+    h->run_backward(c, true);
+    h->run_adam(c);
+    const float l = h->read_loss();
+    if (loss) *loss = l;
+    API_END
+}
+
+int p3d_last_loss(p3d_handle* h, float* loss) {
+    API_BEGIN
+    if (!h || !loss) throw P3dError("null argument");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    *loss = h->read_loss();
+    API_END
+}
+
+int p3d_synchronize(p3d_handle* h) {
+    API_BEGIN
+    if (!h) throw P3dError("null handle");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipStreamSynchronize(h->comm_stream));
+    API_END
+}
+
+int p3d_set_adam(p3d_handle* h, float lr, float beta1, float beta2, float eps) {
+    API_BEGIN
+    if (!h) throw P3dError("null handle");
+    h->lr = lr; h->b1 = beta1; h->b2 = beta2; h->eps = eps;
+    API_END
+}
+
+int p3d_activation_info(p3d_handle* h, const char* name, int64_t shape[5]) {
+    API_BEGIN
+    if (!h || !name) throw P3dError("null argument");
+    auto it = h->named.find(name);
+    if (it == h->named.end()) throw P3dError(std::string("no activation named ") + name);
+    Act* a = it->second;
+    shape[0] = a->N; shape[1] = a->D; shape[2] = a->H; shape[3] = a->W; shape[4] = a->C;
+    API_END
+}
+
+int p3d_get_activation(p3d_handle* h, const char* name, float* host, int64_t count) {
+    API_BEGIN
+    if (!h || !name || !host) throw P3dError("null argument");
+    auto it = h->named.find(name);
+    if (it == h->named.end()) throw P3dError(std::string("no activation named ") + name);
+    Act* a = it->second;
+    if (count != a->rows() * a->C) throw P3dError("activation size mismatch");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    h->download_act(a, host);
+    API_END
+}
+
+int p3d_profile_step(p3d_handle* h, float dropout_rate, uint64_t seed, p3d_op_time* out, int cap) {
+    if (!h) { g_err = "null handle"; return -1; }
+    try {
+        HIPCHECK(hipSetDevice(h->cfg.device));
+        Ctx c; c.training = true; c.drop = dropout_rate; c.seed = seed; c.update_moving = true; c.s = h->stream;
+        const int n = (int)h->ops.size();
+        const int total = 2 * n + 2;
+        std::vector<hipEvent_t> ev(total + 1);
+        for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
+        int k = 0;
+        HIPCHECK(hipMemsetAsync(h->stats_arena, 0, (size_t)h->stats_count * sizeof(double), c.s));
+        HIPCHECK(hipEventRecord(ev[k++], c.s));
+        for (auto& op : h->ops) { op.fwd(c); HIPCHECK(hipEventRecord(ev[k++], c.s)); }
+        h->run_loss(c);
+        HIPCHECK(hipMemsetAsync(h->flat_g, 0, (size_t)h->n_train * sizeof(float), c.s));
+        HIPCHECK(hipMemsetAsync(h->red_arena, 0, (size_t)h->red_count * sizeof(double), c.s));
+        HIPCHECK(hipEventRecord(ev[k++], c.s));
+        for (int i = n - 1; i >= 0; --i) { h->ops[i].bwd(c); HIPCHECK(hipEventRecord(ev[k++], c.s)); }
+        h->run_adam(c);
+        HIPCHECK(hipEventRecord(ev[k++], c.s));
+        HIPCHECK(hipStreamSynchronize(c.s));
+        int w = 0;
+        auto put = [&](const std::string& name, const std::string& kind, float ms, double fl, double by, int bw) {
+            if (w < cap && out) {
+                p3d_op_time& r = out[w];
+                memset(&r, 0, sizeof(r));
+                snprintf(r.name, sizeof(r.name), "%s", name.c_str());
+                snprintf(r.kind, sizeof(r.kind), "%s", kind.c_str());
+                r.ms = ms; r.flops = fl; r.bytes = by; r.backward = bw;
+            }
+            ++w;
+        };
+        float ms = 0;
+        for (int i = 0; i < n; ++i) {
+            HIPCHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            put(h->ops[i].name, h->ops[i].kind, ms, h->ops[i].flops, h->ops[i].bytes, 0);
+        }
+        HIPCHECK(hipEventElapsedTime(&ms, ev[n], ev[n + 1]));
+        put("loss", "smooth_l1", ms, 0, 4.0 * 3 * h->pred->rows(), 0);
+        for (int j = 0; j < n; ++j) {
+            const int i = n - 1 - j;
+            HIPCHECK(hipEventElapsedTime(&ms, ev[n + 1 + j], ev[n + 2 + j]));
+            put(h->ops[i].name, h->ops[i].kind, ms, h->ops[i].bflops, h->ops[i].bbytes, 1);
+        }
+        HIPCHECK(hipEventElapsedTime(&ms, ev[2 * n + 1], ev[2 * n + 2]));
+        put("adam", "adam", ms, 0, 4.0 * 7 * h->n_train, 2);
+        for (auto& e : ev) hipEventDestroy(e);
+        return w;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+int p3d_comm_unique_id(void* id_out) {
+    API_BEGIN
+    static_assert(sizeof(ncclUniqueId) <= P3D_COMM_ID_BYTES, "id size");
+    ncclUniqueId id;
+    NCCLCHECK(ncclGetUniqueId(&id));
+    memset(id_out, 0, P3D_COMM_ID_BYTES);
+    memcpy(id_out, &id, sizeof(id));
+    API_END
+}
+
+int p3d_comm_init(p3d_handle* h, const void* idbytes) {
+    API_BEGIN
+    if (!h || !idbytes) throw P3dError("null argument");
+    if (h->cfg.world_size <= 1) throw P3dError("world_size is 1: no communicator needed");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    ncclUniqueId id;
+    memcpy(&id, idbytes, sizeof(id));
+    NCCLCHECK(ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
+    API_END
+}
+
+// ---- single-operator entry points ------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    float* p = nullptr;
+    explicit DevBuf(int64_t n, const float* host = nullptr) {
+        HIPCHECK(hipMalloc((void**)&p, (size_t)(n > 0 ? n : 1) * 4));
+        if (host) HIPCHECK(hipMemcpy(p, host, (size_t)n * 4, hipMemcpyHostToDevice));
+        else HIPCHECK(hipMemset(p, 0, (size_t)(n > 0 ? n : 1) * 4));
+    }
+    ~DevBuf() { hipFree(p); }
+    void get(float* host, int64_t n) { HIPCHECK(hipDeviceSynchronize()); HIPCHECK(hipMemcpy(host, p, (size_t)n * 4, hipMemcpyDeviceToHost)); }
+};
+int64_t prod5(const int64_t s[5]) { return s[0] * s[1] * s[2] * s[3] * s[4]; }
+bool is_stem_shape(const int64_t xs[5], const int64_t ws[5]) { return xs[4] % 4 != 0 && ws[0] == 1; }
+}  // namespace
+
+int p3d_op_conv3d(int device, const float* x, const int64_t xs[5], const float* w, const int64_t ws[5], const int s[3],
+                  const float* bias, float* y) {
+    API_BEGIN
+    HIPCHECK(hipSetDevice(device));
+    const int k[3] = {(int)ws[0], (int)ws[1], (int)ws[2]};
+    const ConvGeo g = make_geo((int)xs[1], (int)xs[2], (int)xs[3], k, s);
+    const int Cin = (int)xs[4], Cout = (int)ws[4];
+    const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
+    DevBuf dx(prod5(xs), x), dw(prod5(ws), w), dy(ny), db(Cout, bias);
+    IgemmArgs a = igemm_conv_forward(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, bias ? db.p : nullptr, nullptr, 0);
+    if (is_stem_shape(xs, ws)) stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
+    HIPCHECK(p3d_launch_igemm(a, nullptr));
+    dy.get(y, ny);
+    API_END
+}
+
+int p3d_op_conv3d_backprop_input(int device, const float* dyh, const float* w, const int64_t ws[5], const int s[3],
+                                 const int64_t xs[5], float* dxh) {
+    API_BEGIN
+    HIPCHECK(hipSetDevice(device));
+    const int k[3] = {(int)ws[0], (int)ws[1], (int)ws[2]};
+    const ConvGeo g = make_geo((int)xs[1], (int)xs[2], (int)xs[3], k, s);
+    const int Cin = (int)xs[4], Cout = (int)ws[4];
+    const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
+    DevBuf dy(ny, dyh), dw(prod5(ws), w), dx(prod5(xs));
+    auto v = igemm_conv_input_side(g, (int)xs[0], dy.p, Cout, Cout, dx.p, Cin, Cin, dw.p, nullptr, nullptr, 0, true);
+    for (auto& a : v) HIPCHECK(p3d_launch_igemm(a, nullptr));
+    dx.get(dxh, prod5(xs));
+    API_END
+}
+
+int p3d_op_conv3d_backprop_filter(int device, const float* x, const int64_t xs[5], const float* dyh, const int64_t ws[5],
+                                  const int s[3], float* dwh, float* dbh) {
+    API_BEGIN
+    HIPCHECK(hipSetDevice(device));
+    const int k[3] = {(int)ws[0], (int)ws[1], (int)ws[2]};
+    const ConvGeo g = make_geo((int)xs[1], (int)xs[2], (int)xs[3], k, s);
+    const int Cin = (int)xs[4], Cout = (int)ws[4];
+    const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
+    DevBuf dx(prod5(xs), x), dy(ny, dyh), dw(prod5(ws)), db(Cout);
+    WgradArgs a = wgrad_conv(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, dbh ? db.p : nullptr);
+    if (is_stem_shape(xs, ws)) stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
+    HIPCHECK(p3d_launch_wgrad(a, nullptr));
+    dw.get(dwh, prod5(ws));
+    if (dbh) db.get(dbh, Cout);
+    API_END
+}
+
+int p3d_op_conv3d_transpose(int device, const float* x, const int64_t xs[5], const float* kh, const int64_t ks[5],
+                            const int s[3], const float* bias, float* y) {
+    API_BEGIN
+    HIPCHECK(hipSetDevice(device));
+    const int k[3] = {(int)ks[0], (int)ks[1], (int)ks[2]};
+    const ConvGeo g = make_geo((int)xs[1] * s[0], (int)xs[2] * s[1], (int)xs[3] * s[2], k, s);
+    const int Cin = (int)xs[4], Cout = (int)ks[3];
+    if (ks[4] != Cin) throw P3dError("kernel Cin mismatch");
+    const int64_t ny = xs[0] * g.I[0] * g.I[1] * g.I[2] * Cout;
+    DevBuf dx(prod5(xs), x), dk(prod5(ks), kh), dy(ny), db(Cout, bias);
+    auto v = igemm_conv_input_side(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dk.p, bias ? db.p : nullptr, nullptr, 0, true);
+    for (auto& a : v) HIPCHECK(p3d_launch_igemm(a, nullptr));
+    dy.get(y, ny);
+    API_END
+}
+
+static PoolArgs pool_args(const int64_t xs[5], const int k[3], const int s[3], const ConvGeo& g) {
+    PoolArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = (int)xs[0]; a.Di = (int)xs[1]; a.Hi = (int)xs[2]; a.Wi = (int)xs[3]; a.C = (int)xs[4]; a.ldx = a.C;
+    a.Do = g.O[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.ldy = a.C;
+    a.kd = k[0]; a.kh = k[1]; a.kw = k[2]; a.sd = s[0]; a.sh = s[1]; a.sw = s[2];
+    a.pd = g.pad[0]; a.ph = g.pad[1]; a.pw = g.pad[2];
+    a.lddy = a.C; a.lddx = a.C;
+    return a;
+}
+
+int p3d_op_max_pool3d(int device, const float* x, const int64_t xs[5], const int k[3], const int s[3], float* y) {
+    API_BEGIN
+    HIPCHECK(hipSetDevice(device));
+    const ConvGeo g = make_geo((int)xs[1], (int)xs[2], (int)xs[3], k, s);
+    const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * xs[4];
+    DevBuf dx(prod5(xs), x), dy(ny);
+    PoolArgs a = pool_args(xs, k, s, g);
+    a.x = dx.p; a.y = dy.p;
+    HIPCHECK(p3d_maxpool_fwd(a, nullptr));
+    dy.get(y, ny);
+    API_END
+}
+
+int p3d_op_max_pool3d_grad(int device, const float* x, const int64_t xs[5], const int k[3], const int s[3], const float* dyh,
+                           float* dxh) {
+    API_BEGIN
+    HIPCHECK(hipSetDevice(device));
+    const ConvGeo g = make_geo((int)xs[1], (int)xs[2], (int)xs[3], k, s);
+    const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * xs[4];
+    DevBuf dx(prod5(xs), x), dy(ny, dyh), dg(prod5(xs));
+    PoolArgs a = pool_args(xs, k, s, g);
+    a.x = dx.p; a.dy = dy.p; a.dx = dg.p;
+    HIPCHECK(p3d_maxpool_bwd(a, nullptr));
+    dg.get(dxh, prod5(xs));
+    API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// Internal kernel-launch interface of libp3dhip (gfx950 only).
+//
+// Every convolution-like op of the P3D path (tf.nn.conv3d, its two gradients and
+// tf.layers.conv3d_transpose, reference p3d.py:18-27,86,112,125,172,200-217) is
+// expressed on ONE geometry: a "dense side" (the SAME conv's output lattice) and
+// a "gathered side" (the conv's input lattice, reached through kernel taps).
+//   conv forward      : iterate dense side,   gather input  at  g*s + (k - pad)
+//   conv dgrad/deconv : iterate one residue class of the input lattice
+//                       i = g*s + p, gather dense side at g + (p + pad - k)/s
+//   conv wgrad        : reduce over the dense side, X gathered, dY dense
+// so a launch is described by an iteration grid, per-tap integer offsets and an
+// affine output map.  Layout is NDHWC with an explicit row stride (floats per
+// position) so channel slices of concat buffers are addressed in place.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define P3D_MAX_TAPS 27
+
+struct P3dTap {
+    int16_t dd, dh, dw;   // gathered coordinate = g*is + d{d,h,w}
+    int16_t widx;         // which [K][N] slab of the weight tensor
+};
+
+// Implicit-GEMM convolution launch:  Y[m, n] (+)= sum_taps sum_k A[m+tap, k] * B_tap[k, n] (+ bias[n])
+struct IgemmArgs {
+    const float* x;       // gathered operand (already offset to its channel slice)
+    int N, Di, Hi, Wi;    // gathered-side extents
+    int ldx;              // floats per gathered-side position
+    int K;                // reduction channels (Cin of this GEMM)
+    int Gd, Gh, Gw;       // iteration grid per sample; M = N*Gd*Gh*Gw
+    int isd, ish, isw;    // gathered coord = g*is + tap offset
+    float* y;             // output (already offset to its channel slice)
+    int Do, Ho, Wo;       // output extents
+    int ldy;              // floats per output position
+    int Nc;               // output channels of this GEMM
+    int osd, osh, osw, ood, ooh, oow;   // output coord = g*os + oo
+    const float* w;       // weights: slab widx is [K][Nc] (wT=0) or [Nc][K] (wT=1)
+    int wT;
+    const float* bias;    // [Nc] or null
+    double* stats;        // [Nc][2] running (sum, sum of squares) of the stored values, or null
+    int accum;            // 1: Y += result (gradient accumulation)
+    int sigmoid;          // 1: store 1/(1+exp(-v)) (unused by the generic path today)
+    // stem mode (firstconv1, p3d.py:172): the W axis and the 3 input channels are
+    // one contiguous run; a "tap" is a kernel row kh and K = kw*Cin floats.
+    int stem_wfloats;     // Wi*Cin floats per input row (0 = not stem)
+    int stem_wstep;       // floats advanced per output column (sw*Cin)
+    int stem_wpad;        // floats of left padding (pad_w*Cin)
+    int ntaps;
+    P3dTap taps[P3D_MAX_TAPS];
+};
+
+// Weight-gradient launch: dW[widx][k][n] += sum_m Xg[m+tap, k] * dY[m, n]
+struct WgradArgs {
+    const float* x;       // gathered operand (conv input side)
+    int N, Di, Hi, Wi, ldx, K;
+    int Gd, Gh, Gw;       // dense grid (conv output side); M = N*Gd*Gh*Gw
+    int isd, ish, isw;
+    const float* dy;      // dense operand
+    int ldy, Nc;
+    float* dw;            // [slab][K][Nc], accumulated with float atomics
+    float* dbias;         // [Nc] or null (column sums of dy, added by tap 0 / k-tile 0 blocks)
+    int ksplit;           // number of M-range splits (gridDim.y)
+    int stem_wfloats, stem_wstep, stem_wpad;
+    int ntaps;
+    P3dTap taps[P3D_MAX_TAPS];
+};
+
+#ifdef __cplusplus
+extern "C++" {
+#endif
+
+hipError_t p3d_launch_igemm(const IgemmArgs& a, hipStream_t s);
+hipError_t p3d_launch_wgrad(const WgradArgs& a, hipStream_t s);
+
+// ---- BatchNorm (tf.layers.batch_normalization, rank-5, eps 1e-3) ------------------------------
+struct BnParams {          // device pointers, all [C]
+    const float* gamma; const float* beta;
+    float* moving_mean; float* moving_var;
+    double* stats;         // [C][2] sum, sumsq filled by the producer's epilogue
+    float* scale; float* shift;      // y_hat = scale*y + shift
+    float* mean; float* invstd;      // saved for backward
+    int C;
+};
+// use_batch: statistics from `stats` over M rows, else moving stats.  update_moving: momentum 0.99 update.
+hipError_t p3d_bn_finalize(const BnParams& bn, long M, int use_batch, int update_moving, float eps, hipStream_t s);
+
+// Fused normalise/activate/add passes.  Modes (reference p3d.py lines in brackets):
+//  0: z = relu(bn1(y1))                         [58-59, 88+97, 173-174, 201-202]
+//  1: z = relu(bn1(y1) + r)                     [114,133-134 identity residual]
+//  2: z = relu(bn1(y1) + bn2(y2))               [114,127,133-134 projected residual]
+//  3: z = relu(bn1(y1)) + relu(bn2(y2))         [ST_B 65-72]
+//  4: z = r + relu(bn1(y1))                     [ST_C 74-81]
+struct BnApplyArgs {
+    int mode;
+    long M; int C;
+    const float* y1; int ld1; const float* scale1; const float* shift1;
+    const float* y2; int ld2; const float* scale2; const float* shift2;   // y2 doubles as r (modes 1,4)
+    float* z; int ldz;
+    float drop_scale;      // >0: inverted dropout with this keep scale (p3d.py:214), keyed by seed
+    float drop_rate; unsigned long long seed;
+};
+hipError_t p3d_bn_apply(const BnApplyArgs& a, hipStream_t s);
+
+// Backward of the passes above.  Pass 1 reduces per channel sum(dz') and sum(dz' * xhat) into
+// red1/red2 ([C][2] doubles, zeroed by the caller); pass 2 writes the input gradients.
+struct BnBwdArgs {
+    int mode;
+    long M; int C;
+    const float* dz; int lddz;
+    const float* y1; int ld1; const float* scale1; const float* shift1; const float* mean1; const float* invstd1;
+    const float* y2; int ld2; const float* scale2; const float* shift2; const float* mean2; const float* invstd2;
+    const float* gamma1; const float* gamma2;
+    double* red1; double* red2;
+    float* dgamma1; float* dbeta1; float* dgamma2; float* dbeta2;      // parameter grads (written)
+    int batch1, batch2;    // 1: batch statistics were used (full BN backward), 0: inference BN
+    float* dy1; int lddy1; int acc1;
+    float* dy2; int lddy2; int acc2;      // dy2 doubles as dr (modes 1,4)
+    float drop_scale; float drop_rate; unsigned long long seed;
+};
+hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
+hipError_t p3d_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);
+
+// ---- max pool (tf.nn.max_pool3d SAME; p3d.py:177,183,189,195) ---------------------------------
+struct PoolArgs {
+    const float* x; int N, Di, Hi, Wi, C, ldx;
+    float* y; int Do, Ho, Wo, ldy;
+    int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+    // backward
+    const float* dy; int lddy; float* dx; int lddx;
+};
+hipError_t p3d_maxpool_fwd(const PoolArgs& a, hipStream_t s);
+hipError_t p3d_maxpool_bwd(const PoolArgs& a, hipStream_t s);   // atomically adds into dx
+
+// ---- output head: tf.layers.conv3d_transpose(x, 1, 3, 2, 'same') + sigmoid (p3d.py:217-219) ---
+struct HeadArgs {
+    const float* x; int N, D, H, W, C;     // input [N,D,H,W,C], output [N,2D,2H,2W,1]
+    const float* k;                        // kernel [3,3,3,1,C]
+    const float* bias;                     // [1]
+    float* logits; float* pred;            // pre- and post-sigmoid
+    const float* dlogits; float* dx; float* dk; float* dbias;
+};
+hipError_t p3d_head_fwd(const HeadArgs& a, hipStream_t s);
+hipError_t p3d_head_bwd_input(const HeadArgs& a, hipStream_t s);    // dx written
+hipError_t p3d_head_bwd_filter(const HeadArgs& a, hipStream_t s);   // dk, dbias atomically added
+
+// ---- loss: Smooth-L1 sum (utils/network.py:49-62, train.py:159) fused with sigmoid backward ---
+// loss_out: double accumulator (zeroed by caller).  dlogits = dL/dpred * pred*(1-pred).
+hipError_t p3d_smooth_l1(const float* pred, const float* target, long n, double* loss_out,
+                         float* dlogits, int through_sigmoid, hipStream_t s);
+
+// ---- Adam (tf.train.AdamOptimizer, epsilon-hat form; train.py:168) ------------------------------
+hipError_t p3d_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
+                    float eps, hipStream_t s);
+
+// ---- misc ---------------------------------------------------------------------------------------
+hipError_t p3d_add_inplace(float* dst, int lddst, const float* src, int ldsrc, long M, int C, hipStream_t s);
+hipError_t p3d_copy_strided(float* dst, int lddst, const float* src, int ldsrc, long M, int C, hipStream_t s);
+hipError_t p3d_fill_uniform(float* p, long n, float lo, float hi, unsigned long long seed, hipStream_t s);
+hipError_t p3d_colsum(const float* dy, int ld, long M, int C, float* out, hipStream_t s);   // out += column sums
+
+#ifdef __cplusplus
+}
+#endif

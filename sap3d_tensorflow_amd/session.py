@@ -1,0 +1,178 @@
+"""Host-side mirror of the reference's session contract (train.py:175-218, gen_pred.py:48-64,151):
+a P3DSession owns one libp3dhip handle = one built graph with its variables resident in HBM."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import P3dConfig, P3dError, P3dOpTime, check, fptr, lib
+
+STRUCTURES = {"unet": 0}      # train.py:149-154 --structure
+
+
+class P3DSession:
+    """sess = P3DSession(batch=2)  ~  building the graph + tf.Session() in train.py:143-201."""
+
+    def __init__(self, structure="unet", batch=2, frames=16, height=112, width=112, base=64, blocks=(3, 8, 36),
+                 device=0, world_size=1, rank=0, seed=None):
+        if structure not in STRUCTURES:
+            raise ValueError("unknown structure %r (have %s)" % (structure, sorted(STRUCTURES)))
+        self.cfg = P3dConfig()
+        lib().p3d_default_config(C.byref(self.cfg))
+        self.cfg.structure = STRUCTURES[structure]
+        self.cfg.batch, self.cfg.frames, self.cfg.height, self.cfg.width = batch, frames, height, width
+        self.cfg.base = base
+        for i in range(3):
+            self.cfg.blocks[i] = blocks[i]
+        self.cfg.device, self.cfg.world_size, self.cfg.rank = device, world_size, rank
+        self._h = C.c_void_p()
+        check(lib().p3d_create(C.byref(self.cfg), C.byref(self._h)))
+        self.x_shape = (batch, frames, height, width, 3)
+        self.y_shape = (batch, frames, height, width)
+        self.pred_shape = (batch, frames, height, width, 1)
+        self._info = None
+        if seed is not None:
+            self.init_params(seed)
+
+    def close(self):
+        if self._h:
+            lib().p3d_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- variables (tf.global_variables / Saver) ----------------------------------------------
+    def variables(self):
+        """[(name, shape, trainable)] in creation order."""
+        if self._info is None:
+            out = []
+            n = lib().p3d_num_params(self._h)
+            for i in range(n):
+                name = C.c_char_p()
+                nd = C.c_int()
+                shape = (C.c_int64 * 5)()
+                tr = C.c_int()
+                check(lib().p3d_param_info(self._h, i, C.byref(name), C.byref(nd), shape, C.byref(tr)))
+                out.append((name.value.decode(), tuple(shape[:nd.value]), bool(tr.value)))
+            self._info = out
+        return self._info
+
+    def init_params(self, seed=0):
+        """tf.global_variables_initializer (train.py:178,201)."""
+        check(lib().p3d_init_params(self._h, seed))
+
+    def set_param(self, name, value):
+        a = np.ascontiguousarray(value, dtype=np.float32)
+        check(lib().p3d_set_param(self._h, name.encode(), fptr(a), a.size))
+
+    def get_param(self, name):
+        shape = dict((n, s) for n, s, _ in self.variables())[name]
+        a = np.empty(shape, np.float32)
+        check(lib().p3d_get_param(self._h, name.encode(), fptr(a), a.size))
+        return a
+
+    def get_grad(self, name):
+        shape = dict((n, s) for n, s, _ in self.variables())[name]
+        a = np.empty(shape, np.float32)
+        check(lib().p3d_get_grad(self._h, name.encode(), fptr(a), a.size))
+        return a
+
+    def load(self, params):
+        """saver.restore: {tf variable name: array}."""
+        names = set(n for n, _, _ in self.variables())
+        missing = names - set(params)
+        if missing:
+            raise KeyError("checkpoint lacks %d variables, e.g. %s" % (len(missing), sorted(missing)[:3]))
+        for n in names:
+            self.set_param(n, params[n])
+
+    def save(self):
+        """saver.save: {tf variable name: array} of trainables + moving statistics (train.py:180-185)."""
+        return dict((n, self.get_param(n)) for n, _, _ in self.variables())
+
+    # ---- sess.run equivalents --------------------------------------------------------------------
+    def _x(self, x):
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        if a.shape != self.x_shape:
+            raise ValueError("x has shape %s, graph was built for %s" % (a.shape, self.x_shape))
+        return a
+
+    def _y(self, y):
+        a = np.ascontiguousarray(y, dtype=np.float32)
+        if a.shape != self.y_shape:
+            raise ValueError("y has shape %s, graph was built for %s" % (a.shape, self.y_shape))
+        return a
+
+    def forward(self, x, dropout=0.0, training=False, seed=0):
+        """sess.run(pred, {x, dropout, training})  (train.py:225-226, gen_pred.py:151)."""
+        x = self._x(x)
+        pred = np.empty(self.pred_shape, np.float32)
+        check(lib().p3d_forward(self._h, fptr(x), int(bool(training)), float(dropout), seed, fptr(pred)))
+        return pred
+
+    def train_step(self, x, y, dropout=0.5, seed=0):
+        """sess.run([train_op, loss], {x, y, dropout, training: True})  (train.py:217-218) -> loss."""
+        x, y = self._x(x), self._y(y)
+        loss = C.c_float()
+        check(lib().p3d_train_step(self._h, fptr(x), fptr(y), float(dropout), seed, C.byref(loss)))
+        return loss.value
+
+    def backward(self, x, y, dropout=0.0, seed=0):
+        """Forward + loss + gradients without the update -> (loss, pred)."""
+        x, y = self._x(x), self._y(y)
+        loss = C.c_float()
+        pred = np.empty(self.pred_shape, np.float32)
+        check(lib().p3d_backward(self._h, fptr(x), fptr(y), float(dropout), seed, C.byref(loss), fptr(pred)))
+        return loss.value, pred
+
+    def set_adam(self, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8):
+        check(lib().p3d_set_adam(self._h, lr, beta1, beta2, eps))
+
+    def activation(self, name):
+        shape = (C.c_int64 * 5)()
+        check(lib().p3d_activation_info(self._h, name.encode(), shape))
+        a = np.empty(tuple(shape), np.float32)
+        check(lib().p3d_get_activation(self._h, name.encode(), fptr(a), a.size))
+        return a
+
+    # ---- device-resident stepping (bench) ------------------------------------------------------
+    def upload(self, x, y):
+        check(lib().p3d_upload_inputs(self._h, fptr(self._x(x)), fptr(self._y(y)) if y is not None else None))
+
+    def train_step_device(self, dropout=0.0, seed=0):
+        check(lib().p3d_train_step_device(self._h, float(dropout), seed))
+
+    def forward_device(self, training=False, dropout=0.0, seed=0):
+        check(lib().p3d_forward_device(self._h, int(bool(training)), float(dropout), seed))
+
+    def last_loss(self):
+        loss = C.c_float()
+        check(lib().p3d_last_loss(self._h, C.byref(loss)))
+        return loss.value
+
+    def synchronize(self):
+        check(lib().p3d_synchronize(self._h))
+
+    def profile_step(self, dropout=0.0, seed=0):
+        cap = 4096
+        buf = (P3dOpTime * cap)()
+        n = lib().p3d_profile_step(self._h, float(dropout), seed, buf, cap)
+        if n < 0:
+            raise P3dError(lib().p3d_last_error().decode())
+        return [dict(name=r.name.decode(), kind=r.kind.decode(), ms=r.ms, flops=r.flops, bytes=r.bytes,
+                     backward=r.backward) for r in buf[:min(n, cap)]]
+
+    # ---- data parallel -----------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(_lib.P3D_COMM_ID_BYTES)
+        check(lib().p3d_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, id_bytes):
+        buf = C.create_string_buffer(bytes(id_bytes), _lib.P3D_COMM_ID_BYTES)
+        check(lib().p3d_comm_init(self._h, buf))

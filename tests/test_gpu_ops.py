@@ -1,0 +1,109 @@
+"""Op-level parity of the HIP kernels (through the C ABI's p3d_op_* entry points) against the
+oracle in float64.  Tolerance: 2e-5 of the result's max magnitude (fp32 sums of up to ~7k terms;
+the north-star tolerance for the path is 1e-3 relative)."""
+import numpy as np
+import pytest
+
+from oracle import nn
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def close(got, want, tol=TOL):
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got.astype(np.float64) - want).max() / scale
+    assert err < tol, err
+
+
+def rnd(rng, shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+# (xshape, kernel, cout, strides): the shapes of the path at reduced extent + ragged / edge cases
+CONV_CASES = [
+    ((2, 4, 12, 12, 64), (1, 1, 1), 64, (1, 1, 1)),      # conv3_i_1
+    ((2, 4, 12, 12, 64), (1, 1, 1), 256, (1, 1, 1)),     # conv3_i_3
+    ((2, 4, 14, 14, 256), (1, 1, 1), 128, (1, 2, 2)),    # strided 1x1x1 (ids 3, 11)
+    ((1, 4, 13, 11, 32), (1, 1, 1), 48, (1, 2, 2)),      # odd extents, ragged tiles
+    ((2, 4, 12, 12, 64), (1, 3, 3), 64, (1, 1, 1)),      # convS
+    ((2, 4, 12, 12, 64), (3, 1, 1), 64, (1, 1, 1)),      # convT
+    ((2, 2, 7, 7, 256), (1, 3, 3), 256, (1, 1, 1)),      # layer-3 convS
+    ((2, 2, 7, 7, 256), (3, 1, 1), 256, (1, 1, 1)),      # layer-3 convT
+    ((1, 3, 9, 10, 20), (3, 3, 3), 12, (1, 1, 1)),       # general 3x3x3, K not multiple of 32
+    ((1, 4, 10, 10, 16), (3, 3, 3), 24, (2, 2, 2)),      # strided 3x3x3 (deconv input-gradient shape)
+    ((1, 3, 37, 41, 3), (1, 7, 7), 64, (1, 2, 2)),       # stem (Cin=3), odd extents
+    ((2, 4, 32, 32, 3), (1, 7, 7), 16, (1, 2, 2)),       # stem, reduced width
+    ((1, 1, 5, 5, 8), (1, 1, 1), 4, (1, 1, 1)),          # tiny
+]
+
+
+@pytest.mark.parametrize("xs,k,co,s", CONV_CASES)
+def test_conv3d_forward_and_grads(xs, k, co, s):
+    from sap3d_tensorflow_amd import ops
+    rng = np.random.default_rng(abs(hash((xs, k, co, s))) % (2 ** 31))
+    x = rnd(rng, xs)
+    w = rnd(rng, k + (xs[4], co)) * 0.1
+    b = rnd(rng, (co,))
+    want = nn.conv3d_forward(x.astype(np.float64), w.astype(np.float64), s) + b
+    got = ops.conv3d(x, w, s, bias=b)
+    assert got.shape == want.shape
+    close(got, want)
+    dy = rnd(rng, want.shape)
+    want_dw = nn.conv3d_backward_filter(x.astype(np.float64), dy.astype(np.float64), w.shape, s)
+    got_dw, got_db = ops.conv3d_backprop_filter(x, w.shape, dy, s, with_bias=True)
+    close(got_dw, want_dw)
+    close(got_db, dy.astype(np.float64).reshape(-1, co).sum(0))
+    if xs[4] % 4 == 0:
+        want_dx = nn.conv3d_backward_input(dy.astype(np.float64), w.astype(np.float64), s, xs)
+        got_dx = ops.conv3d_backprop_input(xs, w, dy, s)
+        close(got_dx, want_dx)
+
+
+DECONV_CASES = [
+    ((2, 1, 7, 7, 64), (1, 3, 3), 32, (2, 2, 2)),     # deconv1: k1 on the temporal axis
+    ((1, 2, 6, 6, 64), (2, 3, 3), 16, (2, 2, 2)),     # deconv2: k2
+    ((1, 2, 6, 5, 32), (3, 3, 3), 16, (2, 2, 2)),     # deconv3
+    ((1, 1, 3, 3, 16), (3, 3, 3), 8, (4, 4, 4)),      # deconv_pool4 of the concat head: k < s
+    ((1, 2, 5, 5, 16), (3, 3, 3), 8, (1, 1, 1)),      # deconv_pool2 of the concat head: stride 1
+]
+
+
+@pytest.mark.parametrize("xs,k,co,s", DECONV_CASES)
+def test_conv3d_transpose(xs, k, co, s):
+    from sap3d_tensorflow_amd import ops
+    rng = np.random.default_rng(abs(hash((xs, k, co, s))) % (2 ** 31))
+    x = rnd(rng, xs)
+    kern = rnd(rng, k + (co, xs[4])) * 0.1
+    b = rnd(rng, (co,))
+    t = nn.Tape()
+    want = nn.conv3d_transpose(t, nn.Var(x.astype(np.float64)), nn.Var(kern.astype(np.float64)), s,
+                               nn.Var(b.astype(np.float64))).data
+    got = ops.conv3d_transpose(x, kern, s, bias=b)
+    assert got.shape == want.shape
+    close(got, want)
+
+
+POOL_CASES = [
+    ((2, 4, 12, 12, 16), (2, 3, 3), (2, 2, 2)),     # pool1
+    ((2, 4, 6, 6, 32), (2, 1, 1), (2, 1, 1)),       # temporal pools
+    ((1, 3, 7, 9, 8), (2, 3, 3), (2, 2, 2)),        # odd extents: SAME padding on every axis
+]
+
+
+@pytest.mark.parametrize("xs,k,s", POOL_CASES)
+def test_max_pool3d(xs, k, s):
+    from sap3d_tensorflow_amd import ops
+    rng = np.random.default_rng(7)
+    x = np.maximum(rnd(rng, xs), 0)       # post-ReLU input like the path: many tied zeros
+    t = nn.Tape()
+    X = nn.Var(x.astype(np.float64))
+    Y = nn.max_pool3d(t, X, k, s)
+    got = ops.max_pool3d(x, k, s)
+    assert np.array_equal(got, Y.data.astype(np.float32))
+    dy = rnd(rng, Y.data.shape)
+    Y.grad = dy.astype(np.float64)
+    t.ops[-1]()
+    got_dx = ops.max_pool3d_grad(x, k, s, dy)
+    close(got_dx, X.grad)
