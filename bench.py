@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/s of the P3D (p3d_unet) train step -- forward + Smooth-L1 loss +
+backward + Adam -- on synthetic 16x112x112x3 clips, batch 8 per GPU, fp32, on N MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One rank per GPU; each rank owns its shard of clips (weak scaling) and the only exchange is the
+gradient all-reduce (RCCL, inside libp3dhip).  Rank 0 prints ONE JSON line.  Inputs are resident
+in HBM before the timed region.  After the timed region rank 0 runs one extra, untimed step with
+HIP events around every kernel launch (on the launch stream) to fill `roofline`, and -- at N=1
+only -- times the numpy oracle on the host cores for `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+FLOP_PER_CLIP_FWD_BWD = 98.59e9   # algorithmic conv/deconv FLOPs per clip
+
+
+def kernel_table(recs):
+    """Aggregate per-launch HIP-event records by kernel symbol."""
+    agg = {}
+    for r in recs:
+        a = agg.setdefault(r["kernel"], dict(kernel=r["kernel"], launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        a["launches"] += 1
+        a["ms"] += r["ms"]
+        a["flops"] += r["flops"]
+        a["bytes"] += r["bytes"]
+    rows = sorted(agg.values(), key=lambda a: -a["ms"])
+    for a in rows:
+        a["avg_us"] = 1e3 * a["ms"] / a["launches"]
+        a["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
+        a["gbs"] = a["bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0.0
+    return rows
+
+
+def roofline_of(rows):
+    """The dominant kernel (largest share of device time) against the roofline that bounds it."""
+    top = rows[0]
+    ai = top["flops"] / max(top["bytes"], 1.0)
+    if ai >= PEAK_FP32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+        bound, achieved, peak, unit = "mfma", top["tflops"], PEAK_FP32_TFLOPS, "TFLOP/s"
+    else:
+        bound, achieved, peak, unit = "hbm", top["gbs"], PEAK_HBM_GBS, "GB/s"
+    return dict(kernel=top["kernel"], bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit,
+                frac=round(achieved / peak, 4), traffic=None, launches_per_step=top["launches"],
+                avg_launch_us=round(top["avg_us"], 2),
+                flop_per_launch=round(top["flops"] / top["launches"]), bytes_per_launch=round(top["bytes"] / top["launches"]),
+                share_of_device_time=round(top["ms"] / sum(r["ms"] for r in rows), 4))
+
+
+def cpu_baseline(batch=1):
+    """The oracle (numpy restatement, OpenBLAS threads) on one train step of `batch` clips."""
+    from oracle import p3d as oracle
+    params = oracle.init_params(1, "unet", None)
+    x = oracle.synthetic_clip(0, (batch, 16, 112, 112, 3))
+    y = oracle.synthetic_target(3, (batch, 16, 112, 112))
+    state = {"t": 0, "m": {}, "v": {}}
+    t0 = time.time()
+    oracle.train_step(params, state, x, y)
+    dt = time.time() - t0
+    return dict(value=round(batch / dt, 4), unit="clips/s", cores=os.cpu_count(), kind="port",
+                sample="one train step (fwd+loss+bwd+Adam) of %d clip(s) 16x112x112, numpy/OpenBLAS oracle, %.1f s" % (batch, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU (BASELINE.json config: batch 8 per MI355X)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--dump-launches", default=None, help="write every launch record of the profiled step to this CSV")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
+                         (args.gpus, world, args.gpus))
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only
+
+    from sap3d_tensorflow_amd import P3DSession
+    from oracle import p3d as oracle          # synthetic-input law only (dataflow.py:204-208)
+
+    B = args.batch
+    sess = P3DSession("unet", batch=B, device=local_rank, world_size=world, rank=rank, seed=1)
+    if world > 1:
+        ids = [P3DSession.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        sess.comm_init(ids[0])
+    x = oracle.synthetic_clip(rank, (B, 16, 112, 112, 3))
+    y = oracle.synthetic_target(3 + rank, (B, 16, 112, 112))
+    sess.upload(x, y)
+
+    for i in range(args.warmup):
+        sess.train_step_device(0.5, seed=i)
+    sess.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sess.train_step_device(0.5, seed=1000 + i)
+    sess.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    loss = sess.last_loss()
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        value = world * B * args.steps / dt
+        recs = sess.profile_step(0.5, seed=7)
+        rows = kernel_table(recs)
+        if args.dump_launches:
+            with open(args.dump_launches, "w") as f:
+                f.write("op,kernel,phase,ms,flops,bytes\n")
+                for r in recs:
+                    f.write("%s,\"%s\",%d,%.5f,%.0f,%.0f\n" % (r["name"], r["kernel"], r["phase"], r["ms"], r["flops"], r["bytes"]))
+        out = {
+            "metric": "clips/s (16x112x112 fwd+bwd)", "value": round(value, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "p3d_unet (P3D-199 encoder + unet decoder) train step: fwd + Smooth-L1 + bwd + Adam, "
+                                   "16x112x112x3 clips, batch %d per GPU (BASELINE.json configs[2])" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "dropout": 0.5},
+            "model_tflops": round(value * FLOP_PER_CLIP_FWD_BWD / 1e12, 2),
+            "final_loss": loss,
+            "roofline": roofline_of(rows),
+            "kernels": [dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["ms"], 3), avg_us=round(r["avg_us"], 2),
+                             tflops=round(r["tflops"], 2), gbs=round(r["gbs"], 1)) for r in rows[:12]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(1)
+        if args.kernels:
+            for r in rows:
+                print("%-28s n=%5d  %9.3f ms  avg %8.2f us  %7.2f TF/s  %8.1f GB/s" %
+                      (r["kernel"], r["launches"], r["ms"], r["avg_us"], r["tflops"], r["gbs"]), file=sys.stderr)
+        print(json.dumps(out), flush=True)
+    sess.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

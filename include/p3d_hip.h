@@ -91,15 +91,16 @@ int p3d_forward_device(p3d_handle* h, int training, float dropout_rate, uint64_t
 int p3d_last_loss(p3d_handle* h, float* loss);          /* synchronises */
 int p3d_synchronize(p3d_handle* h);
 
-/* ---- per-op timing of one train step with HIP events on the compute stream (the data behind
- *      bench.py's roofline object).  Writes up to `cap` records; returns the number of ops. */
+/* ---- per-launch timing of one train step with HIP events on the stream the kernels are launched
+ *      on (the data behind bench.py's roofline object).  One record per kernel launch, in launch
+ *      order.  Writes up to `cap` records; returns the number of launches. */
 typedef struct p3d_op_time {
-    char name[64];
-    char kind[24];        /* kernel family */
-    double ms;            /* HIP-event duration of the op's launches */
-    double flops;         /* algorithmic FLOPs (2*MACs) */
-    double bytes;         /* algorithmic HBM bytes (operands read once, result written once) */
-    int backward;         /* 0 forward op, 1 backward op, 2 optimiser */
+    char name[64];        /* graph op the launch belongs to (block7/convS, deconv3, ...) */
+    char kernel[48];      /* kernel symbol (igemm_kernel<128,128>, bn_apply_kernel<1>, ...) */
+    double ms;            /* HIP-event duration of this launch */
+    double flops;         /* algorithmic FLOPs of this launch (2*MACs) */
+    double bytes;         /* algorithmic HBM bytes of this launch (operands read once, result written once) */
+    int phase;            /* 0 forward, 1 backward, 2 optimiser */
 } p3d_op_time;
 int p3d_profile_step(p3d_handle* h, float dropout_rate, uint64_t seed, p3d_op_time* out, int cap);
 

@@ -16,8 +16,8 @@ class P3dConfig(C.Structure):
 
 
 class P3dOpTime(C.Structure):
-    _fields_ = [("name", C.c_char * 64), ("kind", C.c_char * 24), ("ms", C.c_double), ("flops", C.c_double),
-                ("bytes", C.c_double), ("backward", C.c_int)]
+    _fields_ = [("name", C.c_char * 64), ("kernel", C.c_char * 48), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double), ("phase", C.c_int)]
 
 
 class P3dError(RuntimeError):

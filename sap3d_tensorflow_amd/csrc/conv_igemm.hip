@@ -251,6 +251,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
 }  // namespace
 
+static bool igemm_use_big(const IgemmArgs& a) {
+    // Tile choice: big tiles when there is enough work to fill 256 CUs with them.
+    const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
+    const long long big = ((M + 127) / 128) * ((a.Nc + 127) / 128);
+    return big >= 512 && a.Nc >= 128;
+}
+
+const char* p3d_igemm_variant(const IgemmArgs& a) { return igemm_use_big(a) ? "igemm_kernel<128,128>" : "igemm_kernel<64,64>"; }
+
 hipError_t p3d_launch_igemm(const IgemmArgs& a, hipStream_t s) {
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     if (M <= 0 || a.Nc <= 0) return hipSuccess;
@@ -258,10 +267,8 @@ hipError_t p3d_launch_igemm(const IgemmArgs& a, hipStream_t s) {
     if (!a.stem_wfloats && ((a.K & 3) || (a.ldx & 3))) return hipErrorInvalidValue;
     if (!a.wT && (a.Nc & 3)) return hipErrorInvalidValue;
     if (a.wT && (a.K & 3)) return hipErrorInvalidValue;
-    // Tile choice: big tiles when there is enough work to fill 256 CUs with them.
-    const long long big = ((M + 127) / 128) * ((a.Nc + 127) / 128);
-    if (big >= 512 && a.Nc >= 128) {
-        const long long blocks = big;
+    if (igemm_use_big(a)) {
+        const long long blocks = ((M + 127) / 128) * ((a.Nc + 127) / 128);
         hipLaunchKernelGGL((igemm_kernel<128, 128>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     } else {
         const long long blocks = ((M + 63) / 64) * ((a.Nc + 63) / 64);

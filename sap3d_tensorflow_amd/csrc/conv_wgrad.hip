@@ -159,6 +159,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
 }  // namespace
 
+const char* p3d_wgrad_variant(const WgradArgs& a) { return (a.K >= 128 && a.Nc >= 128) ? "wgrad_kernel<128,128>" : "wgrad_kernel<64,64>"; }
+
 hipError_t p3d_launch_wgrad(const WgradArgs& a0, hipStream_t s) {
     WgradArgs a = a0;
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;

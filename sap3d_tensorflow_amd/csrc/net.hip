@@ -12,6 +12,7 @@
 
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -77,13 +78,60 @@ struct BN {
     bool used_batch = true;         // what the last forward used
 };
 
+// Per-launch HIP-event timing (p3d_profile_step): one record per kernel launch, on the launch stream.
+struct ProfRec {
+    std::string kernel, op;
+    double flops = 0, bytes = 0;
+    int phase = 0;                 // 0 forward, 1 backward, 2 optimiser
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+struct Prof {
+    std::vector<ProfRec> recs;
+    int phase = 0;
+    std::string cur_op;
+};
+
 struct Ctx {
     bool training = false;
     float drop = 0.f;
     uint64_t seed = 0;
     bool update_moving = false;
     hipStream_t s = nullptr;
+    Prof* prof = nullptr;
 };
+
+template <typename F>
+void launch(const Ctx& c, const char* kernel, double flops, double bytes, F&& f) {
+    if (!c.prof) {
+        HIPCHECK(f());
+        return;
+    }
+    ProfRec r;
+    r.kernel = kernel; r.op = c.prof->cur_op; r.flops = flops; r.bytes = bytes; r.phase = c.prof->phase;
+    HIPCHECK(hipEventCreate(&r.e0));
+    HIPCHECK(hipEventCreate(&r.e1));
+    HIPCHECK(hipEventRecord(r.e0, c.s));
+    HIPCHECK(f());
+    HIPCHECK(hipEventRecord(r.e1, c.s));
+    c.prof->recs.push_back(r);
+}
+
+void launch_igemm(const Ctx& c, const IgemmArgs& a) {
+    const double M = (double)a.N * a.Gd * a.Gh * a.Gw;
+    const double side = (double)a.N * a.Di * a.Hi * a.Wi;
+    const double gathered = std::min(M * std::max(a.ntaps, 1), side);
+    const double Kreal = a.K;
+    launch(c, p3d_igemm_variant(a), 2.0 * M * a.ntaps * Kreal * a.Nc,
+           4.0 * (gathered * Kreal + M * a.Nc * (1 + a.accum) + (double)a.ntaps * Kreal * a.Nc),
+           [&]() { return p3d_launch_igemm(a, c.s); });
+}
+void launch_wgrad(const Ctx& c, const WgradArgs& a) {
+    const double M = (double)a.N * a.Gd * a.Gh * a.Gw;
+    const double side = (double)a.N * a.Di * a.Hi * a.Wi;
+    launch(c, p3d_wgrad_variant(a), 2.0 * M * a.ntaps * (double)a.K * a.Nc,
+           4.0 * (std::min(M * a.ntaps, side) * a.K + M * a.Nc + (double)a.ntaps * a.K * a.Nc),
+           [&]() { return p3d_launch_wgrad(a, c.s); });
+}
 
 struct Op {
     std::string name, kind;
@@ -112,9 +160,20 @@ ConvGeo make_geo(int Di, int Hi, int Wi, const int k[3], const int s[3]) {
 
 inline int pmod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
 
+// firstconv1 (p3d.py:172): kd = 1, the kw x Cin run is contiguous in NDHWC, so a tap = kernel row kh.
+void stemify(const ConvGeo& g, int Cin, int& K, int& ntaps, P3dTap* taps, int& wfloats, int& wstep, int& wpad) {
+    if (g.k[0] != 1) throw P3dError("stem mode needs kd == 1");
+    K = g.k[2] * Cin;
+    ntaps = g.k[1];
+    for (int kh = 0; kh < g.k[1]; ++kh) {
+        taps[kh].dd = 0; taps[kh].dh = (int16_t)(kh - g.pad[1]); taps[kh].dw = 0; taps[kh].widx = (int16_t)kh;
+    }
+    wfloats = g.I[2] * Cin; wstep = g.s[2] * Cin; wpad = g.pad[2] * Cin;
+}
+
 // ---- launch-argument builders on the shared geometry ---------------------------------------------
 IgemmArgs igemm_conv_forward(const ConvGeo& g, int N, const float* x, int ldx, int Cin, float* y, int ldy, int Cout,
-                             const float* w, const float* bias, double* stats, int accum) {
+                             const float* w, const float* bias, double* stats, int accum, bool stem = false) {
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.N = N; a.Di = g.I[0]; a.Hi = g.I[1]; a.Wi = g.I[2]; a.ldx = ldx; a.K = Cin;
@@ -123,6 +182,10 @@ IgemmArgs igemm_conv_forward(const ConvGeo& g, int N, const float* x, int ldx, i
     a.y = y; a.Do = g.O[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.ldy = ldy; a.Nc = Cout;
     a.osd = a.osh = a.osw = 1;
     a.w = w; a.wT = 0; a.bias = bias; a.stats = stats; a.accum = accum;
+    if (stem) {
+        stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
+        return a;
+    }
     int t = 0;
     for (int kd = 0; kd < g.k[0]; ++kd)
         for (int kh = 0; kh < g.k[1]; ++kh)
@@ -189,13 +252,17 @@ std::vector<IgemmArgs> igemm_conv_input_side(const ConvGeo& g, int N, const floa
 }
 
 WgradArgs wgrad_conv(const ConvGeo& g, int N, const float* x, int ldx, int Cin, const float* dy, int ldy, int Cout,
-                     float* dw, float* dbias) {
+                     float* dw, float* dbias, bool stem = false) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.N = N; a.Di = g.I[0]; a.Hi = g.I[1]; a.Wi = g.I[2]; a.ldx = ldx; a.K = Cin;
     a.Gd = g.O[0]; a.Gh = g.O[1]; a.Gw = g.O[2];
     a.isd = g.s[0]; a.ish = g.s[1]; a.isw = g.s[2];
     a.dy = dy; a.ldy = ldy; a.Nc = Cout; a.dw = dw; a.dbias = dbias; a.ksplit = 1;
+    if (stem) {
+        stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
+        return a;
+    }
     int t = 0;
     for (int kd = 0; kd < g.k[0]; ++kd)
         for (int kh = 0; kh < g.k[1]; ++kh)
@@ -209,17 +276,6 @@ WgradArgs wgrad_conv(const ConvGeo& g, int N, const float* x, int ldx, int Cin, 
             }
     a.ntaps = t;
     return a;
-}
-
-// firstconv1 (p3d.py:172): kd = 1, the kw x Cin run is contiguous in NDHWC, so a tap = kernel row kh.
-void stemify(const ConvGeo& g, int Cin, int& K, int& ntaps, P3dTap* taps, int& wfloats, int& wstep, int& wpad) {
-    if (g.k[0] != 1) throw P3dError("stem mode needs kd == 1");
-    K = g.k[2] * Cin;
-    ntaps = g.k[1];
-    for (int kh = 0; kh < g.k[1]; ++kh) {
-        taps[kh].dd = 0; taps[kh].dh = (int16_t)(kh - g.pad[1]); taps[kh].dw = 0; taps[kh].widx = (int16_t)kh;
-    }
-    wfloats = g.I[2] * Cin; wstep = g.s[2] * Cin; wpad = g.pad[2] * Cin;
 }
 
 void zero_strided(float* p, int ld, int64_t rows, int C, hipStream_t s) {
@@ -376,19 +432,17 @@ struct p3d_handle {
         op.first_param_off = w->off;
         op.fwd = [=](const Ctx& c) {
             IgemmArgs a = igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
-                                             bn ? bn_stats(bn) : nullptr, 0);
-            if (stem) stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
-            HIPCHECK(p3d_launch_igemm(a, c.s));
+                                             bn ? bn_stats(bn) : nullptr, 0, stem);
+            launch_igemm(c, a);
         };
         op.bwd = [=](const Ctx& c) {
-            WgradArgs wa = wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr);
-            if (stem) stemify(g, Cin, wa.K, wa.ntaps, wa.taps, wa.stem_wfloats, wa.stem_wstep, wa.stem_wpad);
-            HIPCHECK(p3d_launch_wgrad(wa, c.s));
+            WgradArgs wa = wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr, stem);
+            launch_wgrad(c, wa);
             if (xflag) {
                 const int accum = *xflag;
                 auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, w->p, nullptr, nullptr, accum,
                                                /*include_empty=*/!accum);
-                for (auto& a : v) HIPCHECK(p3d_launch_igemm(a, c.s));
+                for (auto& a : v) launch_igemm(c, a);
             }
         };
         ops.push_back(op);
@@ -413,16 +467,17 @@ struct p3d_handle {
         op.fwd = [=](const Ctx& c) {
             auto v = igemm_conv_input_side(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, kern->p, bias ? bias->p : nullptr,
                                            bn ? bn_stats(bn) : nullptr, 0, true);
-            for (auto& a : v) HIPCHECK(p3d_launch_igemm(a, c.s));
+            for (auto& a : v) launch_igemm(c, a);
         };
         op.bwd = [=](const Ctx& c) {
             // dK[tap][co][ci] = sum dy_big[o][co] * x[i][ci]  (conv wgrad with the roles of x and dy swapped)
             WgradArgs wa = wgrad_conv(g, x->N, y->g, y->ld, Cout, x->p, x->ld, Cin, kern->g, nullptr);
-            HIPCHECK(p3d_launch_wgrad(wa, c.s));
-            if (bias) HIPCHECK(p3d_colsum(y->g, y->ld, y->rows(), Cout, bias->g, c.s));
+            launch_wgrad(c, wa);
+            if (bias)
+                launch(c, "colsum_kernel", 0, 4.0 * y->rows() * Cout, [&]() { return p3d_colsum(y->g, y->ld, y->rows(), Cout, bias->g, c.s); });
             if (xflag) {
                 IgemmArgs a = igemm_conv_forward(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, kern->p, nullptr, nullptr, *xflag);
-                HIPCHECK(p3d_launch_igemm(a, c.s));
+                launch_igemm(c, a);
             }
         };
         ops.push_back(op);
@@ -445,6 +500,9 @@ struct p3d_handle {
         Op op;
         op.name = opname; op.kind = "bn_apply" + std::to_string(mode);
         const double tens = (double)M * C * 4.0;
+        const std::string kn_apply = "bn_apply_kernel<" + std::to_string(mode) + ">";
+        const std::string kn_red = "bn_bwd_reduce_kernel<" + std::to_string(mode) + ">";
+        const std::string kn_bapply = "bn_bwd_apply_kernel<" + std::to_string(mode) + ">";
         op.flops = 0; op.bytes = tens * (y2 ? 3 : 2);
         op.bflops = 0; op.bbytes = tens * (y2 ? 7 : 5);
         op.first_param_off = bn1->gamma->off;
@@ -452,7 +510,9 @@ struct p3d_handle {
         op.fwd = [=](const Ctx& c) {
             auto fin = [&](BN* bn) {
                 bn->used_batch = bn->follows_flag ? c.training : true;
-                HIPCHECK(p3d_bn_finalize(bn_params(bn), M, bn->used_batch, bn->used_batch && c.update_moving, 1e-3f, c.s));
+                launch(c, "bn_finalize_kernel", 0, 64.0 * bn->C, [&]() {
+                    return p3d_bn_finalize(bn_params(bn), M, bn->used_batch, bn->used_batch && c.update_moving, 1e-3f, c.s);
+                });
             };
             fin(bn1);
             if (two) fin(bn2);
@@ -464,7 +524,7 @@ struct p3d_handle {
             if (two) { a.scale2 = bn2->scale; a.shift2 = bn2->shift; }
             a.z = out->p; a.ldz = out->ld;
             if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
-            HIPCHECK(p3d_bn_apply(a, c.s));
+            launch(c, kn_apply.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_apply(a, c.s); });
         };
         op.bwd = [=](const Ctx& c) {
             BnBwdArgs a;
@@ -482,8 +542,8 @@ struct p3d_handle {
                 a.red2 = red_arena + red_off + 2 * C;
             }
             if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
-            HIPCHECK(p3d_bn_bwd_reduce(a, c.s));
-            HIPCHECK(p3d_bn_bwd_apply(a, c.s));
+            launch(c, kn_red.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_bwd_reduce(a, c.s); });
+            launch(c, kn_bapply.c_str(), 0, tens * (y2 ? 5 : 3), [&]() { return p3d_bn_bwd_apply(a, c.s); });
         };
         ops.push_back(op);
         return out;
@@ -504,15 +564,17 @@ struct p3d_handle {
             memset(&a, 0, sizeof(a));
             a.x = x->p; a.N = x->N; a.Di = x->D; a.Hi = x->H; a.Wi = x->W; a.C = x->C; a.ldx = x->ld;
             a.y = out->p; a.Do = g.O[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.ldy = out->ld;
-            a.kd = k[0]; a.kh = k[1]; a.kw = k[2]; a.sd = s[0]; a.sh = s[1]; a.sw = s[2];
+            // NB: k / s are pointers into the builder's stack; only the by-value geometry is safe here
+            a.kd = g.k[0]; a.kh = g.k[1]; a.kw = g.k[2]; a.sd = g.s[0]; a.sh = g.s[1]; a.sw = g.s[2];
             a.pd = g.pad[0]; a.ph = g.pad[1]; a.pw = g.pad[2];
             a.dy = out->g; a.lddy = out->ld; a.dx = x->g; a.lddx = x->ld;
             return a;
         };
-        op.fwd = [=](const Ctx& c) { HIPCHECK(p3d_maxpool_fwd(mk(), c.s)); };
+        const double pool_bytes = op.bytes;
+        op.fwd = [=](const Ctx& c) { launch(c, "maxpool_fwd_kernel", 0, pool_bytes, [&]() { return p3d_maxpool_fwd(mk(), c.s); }); };
         op.bwd = [=](const Ctx& c) {
             if (!*xflag) zero_strided(x->g, x->ld, x->rows(), x->C, c.s);
-            HIPCHECK(p3d_maxpool_bwd(mk(), c.s));
+            launch(c, "maxpool_bwd_kernel", 0, pool_bytes * 2, [&]() { return p3d_maxpool_bwd(mk(), c.s); });
         };
         ops.push_back(op);
         return out;
@@ -667,11 +729,12 @@ struct p3d_handle {
             a.dlogits = d_dlogits; a.dx = x->g; a.dk = k->g; a.dbias = bias->g;
             return a;
         };
-        op.fwd = [=](const Ctx& c) { HIPCHECK(p3d_head_fwd(mk(), c.s)); };
+        const double hf = op.flops, hb = op.bytes;
+        op.fwd = [=](const Ctx& c) { launch(c, "head_fwd_kernel", hf, hb, [&]() { return p3d_head_fwd(mk(), c.s); }); };
         op.bwd = [=](const Ctx& c) {
             if (*xflag) throw P3dError("head input gradient must be the first writer");
-            HIPCHECK(p3d_head_bwd_filter(mk(), c.s));
-            HIPCHECK(p3d_head_bwd_input(mk(), c.s));
+            launch(c, "head_bwd_filter_kernel", hf, hb, [&]() { return p3d_head_bwd_filter(mk(), c.s); });
+            launch(c, "head_bwd_input_kernel", hf, hb, [&]() { return p3d_head_bwd_input(mk(), c.s); });
         };
         ops.push_back(op);
     }
@@ -695,20 +758,36 @@ struct p3d_handle {
     }
 
     // ---- execution -------------------------------------------------------------------------------
+    // P3D_DEBUG_SYNC=1: synchronise and log after every op (fault isolation, not for timing)
+    void debug_sync(const char* dir, const Op& op, const Ctx& c) {
+        static const bool on = getenv("P3D_DEBUG_SYNC") != nullptr;
+        if (!on) return;
+        fprintf(stderr, "[p3d] %s %s (%s) ...", dir, op.name.c_str(), op.kind.c_str());
+        fflush(stderr);
+        HIPCHECK(hipStreamSynchronize(c.s));
+        fprintf(stderr, " ok\n");
+        fflush(stderr);
+    }
     void run_forward(const Ctx& c) {
         HIPCHECK(hipMemsetAsync(stats_arena, 0, (size_t)stats_count * sizeof(double), c.s));
-        for (auto& op : ops) op.fwd(c);
+        for (auto& op : ops) {
+            if (c.prof) c.prof->cur_op = op.name;
+            op.fwd(c);
+            debug_sync("fwd", op, c);
+        }
     }
     void run_loss(const Ctx& c) {
         HIPCHECK(hipMemsetAsync(d_loss, 0, sizeof(double), c.s));
-        HIPCHECK(p3d_smooth_l1(pred->p, d_y, pred->rows(), d_loss, d_dlogits, 1, c.s));
+        launch(c, "smooth_l1_kernel", 0, 12.0 * pred->rows(), [&]() { return p3d_smooth_l1(pred->p, d_y, pred->rows(), d_loss, d_dlogits, 1, c.s); });
     }
     void run_backward(const Ctx& c, bool allreduce) {
         HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
         HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), c.s));
         int64_t hi = n_train;                        // grads in [hi, n_train) are already handed to the comm stream
         for (int i = (int)ops.size() - 1; i >= 0; --i) {
+            if (c.prof) c.prof->cur_op = ops[i].name;
             ops[i].bwd(c);
+            debug_sync("bwd", ops[i], c);
             if (allreduce && comm && ops[i].first_param_off >= 0) {
                 // every parameter at offset >= first_param_off of op i is final now (creation order = forward order)
                 const int64_t lo = ops[i].first_param_off;
@@ -734,7 +813,7 @@ struct p3d_handle {
         ++step;
         const double t = (double)step;
         const float lr_t = (float)(lr * std::sqrt(1.0 - std::pow((double)b2, t)) / (1.0 - std::pow((double)b1, t)));
-        HIPCHECK(p3d_adam(flat_p, flat_g, flat_m, flat_v, n_train, lr_t, b1, b2, eps, c.s));
+        launch(c, "adam_kernel", 0, 28.0 * n_train, [&]() { return p3d_adam(flat_p, flat_g, flat_m, flat_v, n_train, lr_t, b1, b2, eps, c.s); });
     }
 
     void upload(const float* x, const float* y) {
@@ -1027,49 +1106,28 @@ int p3d_profile_step(p3d_handle* h, float dropout_rate, uint64_t seed, p3d_op_ti
     if (!h) { g_err = "null handle"; return -1; }
     try {
         HIPCHECK(hipSetDevice(h->cfg.device));
-        Ctx c; c.training = true; c.drop = dropout_rate; c.seed = seed; c.update_moving = true; c.s = h->stream;
-        const int n = (int)h->ops.size();
-        const int total = 2 * n + 2;
-        std::vector<hipEvent_t> ev(total + 1);
-        for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
-        int k = 0;
-        HIPCHECK(hipMemsetAsync(h->stats_arena, 0, (size_t)h->stats_count * sizeof(double), c.s));
-        HIPCHECK(hipEventRecord(ev[k++], c.s));
-        for (auto& op : h->ops) { op.fwd(c); HIPCHECK(hipEventRecord(ev[k++], c.s)); }
-        h->run_loss(c);
-        HIPCHECK(hipMemsetAsync(h->flat_g, 0, (size_t)h->n_train * sizeof(float), c.s));
-        HIPCHECK(hipMemsetAsync(h->red_arena, 0, (size_t)h->red_count * sizeof(double), c.s));
-        HIPCHECK(hipEventRecord(ev[k++], c.s));
-        for (int i = n - 1; i >= 0; --i) { h->ops[i].bwd(c); HIPCHECK(hipEventRecord(ev[k++], c.s)); }
-        h->run_adam(c);
-        HIPCHECK(hipEventRecord(ev[k++], c.s));
+        Prof prof;
+        Ctx c; c.training = true; c.drop = dropout_rate; c.seed = seed; c.update_moving = true; c.s = h->stream; c.prof = &prof;
+        prof.phase = 0; h->run_forward(c);
+        prof.cur_op = "loss"; h->run_loss(c);
+        prof.phase = 1; h->run_backward(c, true);
+        prof.phase = 2; prof.cur_op = "adam"; h->run_adam(c);
         HIPCHECK(hipStreamSynchronize(c.s));
         int w = 0;
-        auto put = [&](const std::string& name, const std::string& kind, float ms, double fl, double by, int bw) {
+        for (auto& r : prof.recs) {
+            float ms = 0;
+            HIPCHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
             if (w < cap && out) {
-                p3d_op_time& r = out[w];
-                memset(&r, 0, sizeof(r));
-                snprintf(r.name, sizeof(r.name), "%s", name.c_str());
-                snprintf(r.kind, sizeof(r.kind), "%s", kind.c_str());
-                r.ms = ms; r.flops = fl; r.bytes = by; r.backward = bw;
+                p3d_op_time& o = out[w];
+                memset(&o, 0, sizeof(o));
+                snprintf(o.name, sizeof(o.name), "%s", r.op.c_str());
+                snprintf(o.kernel, sizeof(o.kernel), "%s", r.kernel.c_str());
+                o.ms = ms; o.flops = r.flops; o.bytes = r.bytes; o.phase = r.phase;
             }
             ++w;
-        };
-        float ms = 0;
-        for (int i = 0; i < n; ++i) {
-            HIPCHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-            put(h->ops[i].name, h->ops[i].kind, ms, h->ops[i].flops, h->ops[i].bytes, 0);
+            hipEventDestroy(r.e0);
+            hipEventDestroy(r.e1);
         }
-        HIPCHECK(hipEventElapsedTime(&ms, ev[n], ev[n + 1]));
-        put("loss", "smooth_l1", ms, 0, 4.0 * 3 * h->pred->rows(), 0);
-        for (int j = 0; j < n; ++j) {
-            const int i = n - 1 - j;
-            HIPCHECK(hipEventElapsedTime(&ms, ev[n + 1 + j], ev[n + 2 + j]));
-            put(h->ops[i].name, h->ops[i].kind, ms, h->ops[i].bflops, h->ops[i].bbytes, 1);
-        }
-        HIPCHECK(hipEventElapsedTime(&ms, ev[2 * n + 1], ev[2 * n + 2]));
-        put("adam", "adam", ms, 0, 4.0 * 7 * h->n_train, 2);
-        for (auto& e : ev) hipEventDestroy(e);
         return w;
     } catch (const std::exception& e) {
         g_err = e.what();
@@ -1123,8 +1181,8 @@ int p3d_op_conv3d(int device, const float* x, const int64_t xs[5], const float* 
     const int Cin = (int)xs[4], Cout = (int)ws[4];
     const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
     DevBuf dx(prod5(xs), x), dw(prod5(ws), w), dy(ny), db(Cout, bias);
-    IgemmArgs a = igemm_conv_forward(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, bias ? db.p : nullptr, nullptr, 0);
-    if (is_stem_shape(xs, ws)) stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
+    IgemmArgs a = igemm_conv_forward(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, bias ? db.p : nullptr, nullptr, 0,
+                                     is_stem_shape(xs, ws));
     HIPCHECK(p3d_launch_igemm(a, nullptr));
     dy.get(y, ny);
     API_END
@@ -1154,8 +1212,7 @@ int p3d_op_conv3d_backprop_filter(int device, const float* x, const int64_t xs[5
     const int Cin = (int)xs[4], Cout = (int)ws[4];
     const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
     DevBuf dx(prod5(xs), x), dy(ny, dyh), dw(prod5(ws)), db(Cout);
-    WgradArgs a = wgrad_conv(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, dbh ? db.p : nullptr);
-    if (is_stem_shape(xs, ws)) stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
+    WgradArgs a = wgrad_conv(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, dbh ? db.p : nullptr, is_stem_shape(xs, ws));
     HIPCHECK(p3d_launch_wgrad(a, nullptr));
     dw.get(dwh, prod5(ws));
     if (dbh) db.get(dbh, Cout);

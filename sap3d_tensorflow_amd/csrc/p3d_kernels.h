@@ -72,6 +72,8 @@ extern "C++" {
 
 hipError_t p3d_launch_igemm(const IgemmArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad(const WgradArgs& a, hipStream_t s);
+const char* p3d_igemm_variant(const IgemmArgs& a);     // kernel symbol the launcher will pick
+const char* p3d_wgrad_variant(const WgradArgs& a);
 
 // ---- BatchNorm (tf.layers.batch_normalization, rank-5, eps 1e-3) ------------------------------
 struct BnParams {          // device pointers, all [C]

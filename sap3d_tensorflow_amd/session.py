@@ -158,13 +158,13 @@ class P3DSession:
         check(lib().p3d_synchronize(self._h))
 
     def profile_step(self, dropout=0.0, seed=0):
-        cap = 4096
+        cap = 16384
         buf = (P3dOpTime * cap)()
         n = lib().p3d_profile_step(self._h, float(dropout), seed, buf, cap)
         if n < 0:
             raise P3dError(lib().p3d_last_error().decode())
-        return [dict(name=r.name.decode(), kind=r.kind.decode(), ms=r.ms, flops=r.flops, bytes=r.bytes,
-                     backward=r.backward) for r in buf[:min(n, cap)]]
+        return [dict(name=r.name.decode(), kernel=r.kernel.decode(), ms=r.ms, flops=r.flops, bytes=r.bytes,
+                     phase=r.phase) for r in buf[:min(n, cap)]]
 
     # ---- data parallel -----------------------------------------------------------------------------
     @staticmethod
