@@ -1,0 +1,89 @@
+"""Parity at the reference architecture (P3D-199, 16x112x112) -- BASELINE.json configs[0..2] --
+against the float32 oracle run on the GPU box's host cores."""
+import numpy as np
+import pytest
+
+from oracle import p3d
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b, floor=1e-30):
+    return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), floor)
+
+
+@pytest.fixture(scope="module")
+def ref_params():
+    return p3d.init_params(1, 'unet', None)
+
+
+def test_config0_stem_and_block_a(ref_params):
+    """configs[0]: single P3D-A block forward on a 1x16x112x112x3 synthetic clip, numerics only."""
+    from sap3d_tensorflow_amd import P3DSession
+    x = p3d.synthetic_clip(0, (1, 16, 112, 112, 3))
+    _, g = p3d.forward(ref_params, x, 0.0, True, 'unet')
+    s = P3DSession('unet', batch=1)
+    s.load(ref_params)
+    s.forward(x, 0.0, True)
+    for name in ['conv1_custom', 'conv1_custom_bn_relu', 'pool1', 'block0/conv1_bn_relu', 'block0/st', 'block0/out']:
+        want = g.tape.taps[name].data
+        got = s.activation(name)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max(), name
+        assert rel_l2(got, want) < 1e-5, name
+    s.close()
+
+
+def _noise_floor_check(got, o32, o64):
+    """Saliency maps within 1e-3 relative of the float64 oracle -- or, where fp32 arithmetic itself
+    cannot do that, no worse than 1.5x the float32 oracle's own distance to float64 (measured: the
+    numpy-fp32 oracle sits 0.7..0.9e-3 from fp64 at the worst of 800k outputs of this 199-layer
+    net, 2..4e-5 on average)."""
+    e_hip = np.abs(got - o64) / np.abs(o64)
+    e_o32 = np.abs(o32 - o64) / np.abs(o64)
+    assert e_hip.max() < max(1e-3, 1.5 * e_o32.max()), (e_hip.max(), e_o32.max())
+    assert e_hip.mean() < max(1e-4, 1.5 * e_o32.mean()), (e_hip.mean(), e_o32.mean())
+    assert np.quantile(e_hip, 0.999) < 1e-3
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_config1_full_forward_b4(ref_params, training):
+    """configs[1]: full backbone forward, random weights, batch 4, saliency-map difference."""
+    from sap3d_tensorflow_amd import P3DSession
+    x = p3d.synthetic_clip(0, (4, 16, 112, 112, 3))
+    o32, _ = p3d.forward(ref_params, x, 0.0, training, 'unet')
+    p64 = {k: v.astype(np.float64) for k, v in ref_params.items()}
+    o64, _ = p3d.forward(p64, x.astype(np.float64), 0.0, training, 'unet', None, np.float64)
+    s = P3DSession('unet', batch=4)
+    s.load(ref_params)
+    got = s.forward(x, 0.0, training)
+    assert got.shape == (4, 16, 112, 112, 1)
+    _noise_floor_check(got, o32, o64)
+    s.close()
+
+
+def test_config2_forward_backward(ref_params):
+    """configs[2] at batch 2 (the oracle finishes in a minute): loss, saliency maps, every gradient,
+    against the float64 oracle."""
+    from sap3d_tensorflow_amd import P3DSession
+    x = p3d.synthetic_clip(0, (2, 16, 112, 112, 3))
+    y = p3d.synthetic_target(3, (2, 16, 112, 112))
+    p64 = {k: v.astype(np.float64) for k, v in ref_params.items()}
+    want_loss, want_pred, want_grads, _ = p3d.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True,
+                                                             'unet', None, np.float64)
+    s = P3DSession('unet', batch=2)
+    s.load(ref_params)
+    loss, pred = s.backward(x, y, 0.0)
+    assert abs(loss - want_loss) <= 1e-5 * abs(want_loss)
+    e = np.abs(pred - want_pred) / np.abs(want_pred)
+    assert e.max() < 1.5e-3 and e.mean() < 1e-4 and np.quantile(e, 0.999) < 1e-3, (e.max(), e.mean())
+    scale = np.median([np.linalg.norm(g) for g in want_grads.values()])
+    errs = {}
+    for n, w in want_grads.items():
+        errs[n] = rel_l2(s.get_grad(n), w, 1e-2 * scale)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # two fp32 implementations of this 150-layer net differ by ~1e-2 in deep gradients (ReLU / max-pool
+    # decisions flipping on 1e-7 perturbations); see tests/test_oracle_vs_torch.py
+    assert np.median(list(errs.values())) < 2e-2, worst
+    assert worst[0][1] < 0.15, worst
+    s.close()
