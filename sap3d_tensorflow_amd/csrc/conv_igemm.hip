@@ -243,8 +243,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         }
         __syncthreads();
         if (tid < BN && (n0 + tid) < p.Nc) {
-            unsafeAtomicAdd(&p.stats[2 * (n0 + tid) + 0], (double)(sred[0][tid][0] + sred[1][tid][0]));
-            unsafeAtomicAdd(&p.stats[2 * (n0 + tid) + 1], (double)(sred[0][tid][1] + sred[1][tid][1]));
+            double* st = p.stats + (size_t)(blockIdx.x % P3D_STAT_REPLICAS) * 2 * p.Nc;
+            unsafeAtomicAdd(&st[2 * (n0 + tid) + 0], (double)(sred[0][tid][0] + sred[1][tid][0]));
+            unsafeAtomicAdd(&st[2 * (n0 + tid) + 1], (double)(sred[0][tid][1] + sred[1][tid][1]));
         }
     }
 }

@@ -40,8 +40,13 @@ __global__ void bn_finalize_kernel(BnParams bn, double invM, int use_batch, int 
     if (c >= bn.C) return;
     double mean, var;
     if (use_batch) {
-        mean = bn.stats[2 * c] * invM;
-        var = bn.stats[2 * c + 1] * invM - mean * mean;
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < P3D_STAT_REPLICAS; ++r) {
+            s1 += bn.stats[(size_t)r * 2 * bn.C + 2 * c];
+            s2 += bn.stats[(size_t)r * 2 * bn.C + 2 * c + 1];
+        }
+        mean = s1 * invM;
+        var = s2 * invM - mean * mean;
         if (var < 0.0) var = 0.0;
         if (update_moving) {      // moving -= (moving - batch) * (1 - 0.99)   (biased variance, Appendix A.4)
             bn.moving_mean[c] -= (bn.moving_mean[c] - (float)mean) * (1.0f - 0.99f);
@@ -57,6 +62,41 @@ __global__ void bn_finalize_kernel(BnParams bn, double invM, int use_batch, int 
     bn.shift[c] = (float)((double)bn.beta[c] - mean * (double)bn.gamma[c] * inv);
     bn.mean[c] = (float)mean;
     bn.invstd[c] = (float)inv;
+}
+
+// Per-channel (sum, sumsq) of y.  Thread = one float4 channel group, RPI rows per block pass.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int ld, long long M, int C, double* stats) {
+    __shared__ float red[256][8];
+    const int c4n = C >> 2;
+    const int rpi = 256 / c4n;
+    const int tid = threadIdx.x;
+    const int sub = tid / c4n;
+    const int cg = tid - sub * c4n;
+    const int c = cg << 2;
+    float4 s1 = f4(0.f), s2 = f4(0.f);
+    if (sub < rpi)
+        for (long long row = (long long)blockIdx.x * rpi + sub; row < M; row += (long long)gridDim.x * rpi) {
+            const float4 v = ld4(y + row * ld + c);
+            s1 = add4(s1, v);
+            s2 = fma4(v, v, s2);
+        }
+    float* r = red[tid];
+    r[0] = s1.x; r[1] = s1.y; r[2] = s1.z; r[3] = s1.w; r[4] = s2.x; r[5] = s2.y; r[6] = s2.z; r[7] = s2.w;
+    __syncthreads();
+    if (tid < c4n) {
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = 0.f;
+        for (int s = 0; s < rpi; ++s)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] += red[s * c4n + tid][q];
+        double* st = stats + (size_t)(blockIdx.x % P3D_STAT_REPLICAS) * 2 * C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsafeAtomicAdd(&st[2 * (c + q) + 0], (double)t[q]);
+            unsafeAtomicAdd(&st[2 * (c + q) + 1], (double)t[4 + q]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -141,21 +181,47 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
         for (int s = 0; s < rpi; ++s)
 #pragma unroll
             for (int q = 0; q < NV; ++q) t[q] += red[s * c4n + tid][q];
+        const size_t rep = (size_t)(blockIdx.x % P3D_STAT_REPLICAS) * 2 * a.C;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            unsafeAtomicAdd(&a.red1[2 * (c + q) + 0], (double)t[q]);
-            unsafeAtomicAdd(&a.red1[2 * (c + q) + 1], (double)t[4 + q]);
+            unsafeAtomicAdd(&a.red1[rep + 2 * (c + q) + 0], (double)t[q]);
+            unsafeAtomicAdd(&a.red1[rep + 2 * (c + q) + 1], (double)t[4 + q]);
             if (TWO) {
-                unsafeAtomicAdd(&a.red2[2 * (c + q) + 0], (double)t[8 + q]);
-                unsafeAtomicAdd(&a.red2[2 * (c + q) + 1], (double)t[12 + q]);
+                unsafeAtomicAdd(&a.red2[rep + 2 * (c + q) + 0], (double)t[8 + q]);
+                unsafeAtomicAdd(&a.red2[rep + 2 * (c + q) + 1], (double)t[12 + q]);
             }
         }
     }
 }
 
-__device__ __forceinline__ float4 ldred(const double* r, int c, int which, float scale) {
-    return make_float4((float)(r[2 * c + which] * scale), (float)(r[2 * (c + 1) + which] * scale),
-                       (float)(r[2 * (c + 2) + which] * scale), (float)(r[2 * (c + 3) + which] * scale));
+// Folds the replicated sums: coef[c] = (sum g / M, sum g*xhat / M) and the BN parameter gradients
+// (each BN parameter is produced exactly once per step, so they are written, not accumulated).
+__global__ void bn_bwd_finalize_kernel(BnBwdArgs a, int two) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    const double invM = 1.0 / (double)a.M;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < P3D_STAT_REPLICAS; ++r) {
+        s1 += a.red1[(size_t)r * 2 * a.C + 2 * c];
+        s2 += a.red1[(size_t)r * 2 * a.C + 2 * c + 1];
+    }
+    a.dbeta1[c] = (float)s1; a.dgamma1[c] = (float)s2;
+    a.coef1[2 * c] = (float)(s1 * invM); a.coef1[2 * c + 1] = (float)(s2 * invM);
+    if (two) {
+        s1 = 0.0; s2 = 0.0;
+        for (int r = 0; r < P3D_STAT_REPLICAS; ++r) {
+            s1 += a.red2[(size_t)r * 2 * a.C + 2 * c];
+            s2 += a.red2[(size_t)r * 2 * a.C + 2 * c + 1];
+        }
+        a.dbeta2[c] = (float)s1; a.dgamma2[c] = (float)s2;
+        a.coef2[2 * c] = (float)(s1 * invM); a.coef2[2 * c + 1] = (float)(s2 * invM);
+    }
+}
+
+__device__ __forceinline__ void ldcoef(const float* coef, int c, float4& c1, float4& c2) {
+    const float4 lo = ld4(coef + 2 * c), hi = ld4(coef + 2 * c + 4);     // (s,x,s,x) (s,x,s,x)
+    c1 = make_float4(lo.x, lo.z, hi.x, hi.z);
+    c2 = make_float4(lo.y, lo.w, hi.y, hi.w);
 }
 
 template <int MODE>
@@ -163,15 +229,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     constexpr bool TWO = (MODE == 2 || MODE == 3);
     const int c4n = a.C >> 2;
     const long long total = a.M * c4n;
-    const float invM = 1.0f / (float)a.M;
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    // parameter gradients (each BN parameter is produced exactly once per step)
-    if (gtid < a.C) {
-        const int c = (int)gtid;
-        a.dbeta1[c] = (float)a.red1[2 * c];
-        a.dgamma1[c] = (float)a.red1[2 * c + 1];
-        if (TWO) { a.dbeta2[c] = (float)a.red2[2 * c]; a.dgamma2[c] = (float)a.red2[2 * c + 1]; }
-    }
     for (long long i = gtid; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long row = i / c4n;
         const int c = (int)(i - row * c4n) << 2;
@@ -182,7 +240,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
             float4 d;
             if (a.batch1) {
                 const float4 xh = mul4(sub4(y1, ld4(a.mean1 + c)), ld4(a.invstd1 + c));
-                const float4 c1 = ldred(a.red1, c, 0, invM), c2 = ldred(a.red1, c, 1, invM);
+                float4 c1, c2;
+                ldcoef(a.coef1, c, c1, c2);
                 d = mul4(k, sub4(sub4(g1, c1), mul4(xh, c2)));
             } else d = mul4(k, g1);
             float* dst = a.dy1 + row * a.lddy1 + c;
@@ -195,7 +254,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
                 const float4 k = mul4(ld4(a.gamma2 + c), ld4(a.invstd2 + c));
                 if (a.batch2) {
                     const float4 xh = mul4(sub4(y2, ld4(a.mean2 + c)), ld4(a.invstd2 + c));
-                    const float4 c1 = ldred(a.red2, c, 0, invM), c2 = ldred(a.red2, c, 1, invM);
+                    float4 c1, c2;
+                    ldcoef(a.coef2, c, c1, c2);
                     d = mul4(k, sub4(sub4(g2, c1), mul4(xh, c2)));
                 } else d = mul4(k, g2);
             } else d = g2;            // residual branch (modes 1, 4)
@@ -367,6 +427,16 @@ hipError_t p3d_bn_finalize(const BnParams& bn, long M, int use_batch, int update
     return hipGetLastError();
 }
 
+hipError_t p3d_bn_stats(const float* y, int ld, long M, int C, double* stats, hipStream_t s) {
+    if ((C & 3) || C > 1024 || (ld & 3)) return hipErrorInvalidValue;
+    const int rpi = 256 / (C >> 2);
+    long long blocks = (M + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, ld, (long long)M, C, stats);
+    return hipGetLastError();
+}
+
 hipError_t p3d_bn_apply(const BnApplyArgs& a, hipStream_t s) {
     if ((a.C & 3) || (a.ld1 & 3) || (a.ldz & 3)) return hipErrorInvalidValue;
     const unsigned g = grid_for(a.M * (a.C >> 2));
@@ -384,9 +454,9 @@ hipError_t p3d_bn_apply(const BnApplyArgs& a, hipStream_t s) {
 hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
     if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
     const int rpi = 256 / (a.C >> 2);
-    long long blocks = (a.M + (long long)rpi * 16 - 1) / ((long long)rpi * 16);
+    long long blocks = (a.M + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
     if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;
     const unsigned g = (unsigned)blocks;
     switch (a.mode) {
         case 0: hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, dim3(g), dim3(256), 0, s, a); break;
@@ -399,10 +469,14 @@ hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t p3d_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s, a, (a.mode == 2 || a.mode == 3) ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t p3d_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s) {
     if (a.C & 3) return hipErrorInvalidValue;
     unsigned g = grid_for(a.M * (a.C >> 2));
-    if ((long long)g * 256 < a.C) g = (a.C + 255) / 256;
     switch (a.mode) {
         case 0: hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(g), dim3(256), 0, s, a); break;
         case 1: hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(g), dim3(256), 0, s, a); break;

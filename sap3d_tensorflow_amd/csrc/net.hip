@@ -116,15 +116,61 @@ void launch(const Ctx& c, const char* kernel, double flops, double bytes, F&& f)
     c.prof->recs.push_back(r);
 }
 
-void launch_igemm(const Ctx& c, const IgemmArgs& a) {
+const float* g_zero_page = nullptr;      // 1 KiB of zeros (device), set by p3d_create / op entry points
+
+void igemm_work(const IgemmArgs& a, double& flops, double& bytes) {
     const double M = (double)a.N * a.Gd * a.Gh * a.Gw;
     const double side = (double)a.N * a.Di * a.Hi * a.Wi;
     const double gathered = std::min(M * std::max(a.ntaps, 1), side);
-    const double Kreal = a.K;
-    launch(c, p3d_igemm_variant(a), 2.0 * M * a.ntaps * Kreal * a.Nc,
-           4.0 * (gathered * Kreal + M * a.Nc * (1 + a.accum) + (double)a.ntaps * Kreal * a.Nc),
-           [&]() { return p3d_launch_igemm(a, c.s); });
+    flops = 2.0 * M * a.ntaps * (double)a.K * a.Nc;
+    bytes = 4.0 * (gathered * a.K + M * a.Nc * (1 + a.accum) + (double)a.ntaps * a.K * a.Nc);
 }
+
+void launch_igemm(const Ctx& c, const IgemmArgs& a0, int allow_split = 0) {
+    IgemmArgs a = a0;
+    double fl, by;
+    igemm_work(a, fl, by);
+    if (a.stem_wfloats) {
+        launch(c, p3d_igemm_variant(a), fl, by, [&]() { return p3d_launch_igemm(a, c.s); });
+        return;
+    }
+    a.zeros = g_zero_page;
+    const P3dIgemmPlan pl = p3d_igemm2_plan(a, allow_split);
+    launch(c, pl.name, fl, by, [&]() { return p3d_launch_igemm2(a, pl, c.s); });
+}
+
+void zero_strided(float* p, int ld, int64_t rows, int C, hipStream_t s);
+
+// A group of implicit-GEMM launches that together produce one output tensor (one conv forward,
+// or the residue classes of an input gradient / transposed conv).  Lets small problems slice K
+// across blocks: the output is zeroed first (unless it already holds a value to accumulate into)
+// and every launch then adds into it; statistics move to a separate pass.
+void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld, int64_t rows, int C, bool accumulate,
+                     double* stats) {
+    bool any_split = false;
+    for (auto& a : v) {
+        if (a.stem_wfloats) continue;
+        IgemmArgs t = a;
+        t.stats = nullptr; t.accum = 0;
+        if (p3d_igemm2_plan(t, 1).splits > 1) any_split = true;
+    }
+    if (!any_split) {
+        for (auto& a : v) { a.accum = accumulate ? 1 : 0; a.stats = stats; launch_igemm(c, a, 0); }
+        return;
+    }
+    if (!accumulate) zero_strided(out, ld, rows, C, c.s);
+    for (auto& a : v) {
+        a.stats = nullptr;
+        IgemmArgs t = a;
+        t.accum = 0;
+        const bool split = p3d_igemm2_plan(t, 1).splits > 1;
+        a.accum = split ? 0 : 1;          // split launches add atomically; whole-K launches add with a plain RMW
+        launch_igemm(c, a, split ? 1 : 0);
+    }
+    if (stats)
+        launch(c, "bn_stats_kernel", 0, 4.0 * rows * C, [&]() { return p3d_bn_stats(out, ld, rows, C, stats, c.s); });
+}
+
 void launch_wgrad(const Ctx& c, const WgradArgs& a) {
     const double M = (double)a.N * a.Gd * a.Gh * a.Gw;
     const double side = (double)a.N * a.Di * a.Hi * a.Wi;
@@ -285,6 +331,17 @@ void zero_strided(float* p, int ld, int64_t rows, int C, hipStream_t s) {
 
 }  // namespace
 
+namespace {
+void ensure_zero_page() {
+    // one page per process; igemm2 reads it for padded rows and channel tails
+    if (g_zero_page) return;
+    float* p = nullptr;
+    HIPCHECK(hipMalloc((void**)&p, 1024));
+    HIPCHECK(hipMemset(p, 0, 1024));
+    g_zero_page = p;
+}
+}  // namespace
+
 // ==================================================================================================
 struct p3d_handle {
     p3d_config cfg;
@@ -398,7 +455,7 @@ struct p3d_handle {
         bn->beta = add_param(bn->name + "/beta", {C}, true, INIT_ZEROS);
         bn->mm = add_param(bn->name + "/moving_mean", {C}, false, INIT_ZEROS);
         bn->mv = add_param(bn->name + "/moving_variance", {C}, false, INIT_ONES);
-        bn->stats_off = stats_count; stats_count += 2 * C;
+        bn->stats_off = stats_count; stats_count += (int64_t)P3D_STAT_REPLICAS * 2 * C;
         const int64_t o = bnbuf_count; bnbuf_count += 4 * (int64_t)C;
         late_bind.push_back([this, bn, o, C]() {
             bn->scale = bnbuf + o; bn->shift = bnbuf + o + C; bn->mean = bnbuf + o + 2 * C; bn->invstd = bnbuf + o + 3 * C;
@@ -431,9 +488,9 @@ struct p3d_handle {
         op.bbytes = op.bytes * (x->g ? 2 : 1);
         op.first_param_off = w->off;
         op.fwd = [=](const Ctx& c) {
-            IgemmArgs a = igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
-                                             bn ? bn_stats(bn) : nullptr, 0, stem);
-            launch_igemm(c, a);
+            std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
+                                                        nullptr, 0, stem)};
+            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, bn ? bn_stats(bn) : nullptr);
         };
         op.bwd = [=](const Ctx& c) {
             WgradArgs wa = wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr, stem);
@@ -442,7 +499,7 @@ struct p3d_handle {
                 const int accum = *xflag;
                 auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, w->p, nullptr, nullptr, accum,
                                                /*include_empty=*/!accum);
-                for (auto& a : v) launch_igemm(c, a);
+                run_igemm_group(c, v, x->g, x->ld, x->rows(), Cin, accum != 0, nullptr);
             }
         };
         ops.push_back(op);
@@ -466,8 +523,8 @@ struct p3d_handle {
         op.first_param_off = kern->off;
         op.fwd = [=](const Ctx& c) {
             auto v = igemm_conv_input_side(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, kern->p, bias ? bias->p : nullptr,
-                                           bn ? bn_stats(bn) : nullptr, 0, true);
-            for (auto& a : v) launch_igemm(c, a);
+                                           nullptr, 0, true);
+            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, bn ? bn_stats(bn) : nullptr);
         };
         op.bwd = [=](const Ctx& c) {
             // dK[tap][co][ci] = sum dy_big[o][co] * x[i][ci]  (conv wgrad with the roles of x and dy swapped)
@@ -476,8 +533,8 @@ struct p3d_handle {
             if (bias)
                 launch(c, "colsum_kernel", 0, 4.0 * y->rows() * Cout, [&]() { return p3d_colsum(y->g, y->ld, y->rows(), Cout, bias->g, c.s); });
             if (xflag) {
-                IgemmArgs a = igemm_conv_forward(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, kern->p, nullptr, nullptr, *xflag);
-                launch_igemm(c, a);
+                std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, kern->p, nullptr, nullptr, *xflag)};
+                run_igemm_group(c, v, x->g, x->ld, x->rows(), Cin, *xflag != 0, nullptr);
             }
         };
         ops.push_back(op);
@@ -494,7 +551,9 @@ struct p3d_handle {
         if (y2) f2 = consume(y2);
         const bool two = (mode == 2 || mode == 3);
         const int64_t red_off = red_count;
-        red_count += (two ? 4 : 2) * (int64_t)y1->C;
+        red_count += (two ? 2 : 1) * (int64_t)P3D_STAT_REPLICAS * 2 * y1->C;
+        const int64_t coef_off = bnbuf_count;
+        bnbuf_count += (two ? 4 : 2) * (int64_t)y1->C;
         const int64_t M = y1->rows();
         const int C = y1->C;
         Op op;
@@ -533,16 +592,17 @@ struct p3d_handle {
             a.dz = out->g; a.lddz = out->ld;
             a.y1 = y1->p; a.ld1 = y1->ld; a.scale1 = bn1->scale; a.shift1 = bn1->shift; a.mean1 = bn1->mean; a.invstd1 = bn1->invstd;
             a.gamma1 = bn1->gamma->p; a.dgamma1 = bn1->gamma->g; a.dbeta1 = bn1->beta->g; a.batch1 = bn1->used_batch;
-            a.red1 = red_arena + red_off;
+            a.red1 = red_arena + red_off; a.coef1 = bnbuf + coef_off;
             a.dy1 = y1->g; a.lddy1 = y1->ld; a.acc1 = 0;
             if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; a.dy2 = y2->g; a.lddy2 = y2->ld; a.acc2 = *f2; }
             if (two) {
                 a.scale2 = bn2->scale; a.shift2 = bn2->shift; a.mean2 = bn2->mean; a.invstd2 = bn2->invstd;
                 a.gamma2 = bn2->gamma->p; a.dgamma2 = bn2->gamma->g; a.dbeta2 = bn2->beta->g; a.batch2 = bn2->used_batch;
-                a.red2 = red_arena + red_off + 2 * C;
+                a.red2 = red_arena + red_off + (int64_t)P3D_STAT_REPLICAS * 2 * C; a.coef2 = bnbuf + coef_off + 2 * C;
             }
             if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
             launch(c, kn_red.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_bwd_reduce(a, c.s); });
+            launch(c, "bn_bwd_finalize_kernel", 0, 64.0 * C, [&]() { return p3d_bn_bwd_finalize(a, c.s); });
             launch(c, kn_bapply.c_str(), 0, tens * (y2 ? 5 : 3), [&]() { return p3d_bn_bwd_apply(a, c.s); });
         };
         ops.push_back(op);
@@ -878,6 +938,7 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         HIPCHECK(hipSetDevice(cfg->device));
         h = new p3d_handle();
         h->cfg = *cfg;
+        ensure_zero_page();
         HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
@@ -1183,7 +1244,8 @@ int p3d_op_conv3d(int device, const float* x, const int64_t xs[5], const float* 
     DevBuf dx(prod5(xs), x), dw(prod5(ws), w), dy(ny), db(Cout, bias);
     IgemmArgs a = igemm_conv_forward(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, bias ? db.p : nullptr, nullptr, 0,
                                      is_stem_shape(xs, ws));
-    HIPCHECK(p3d_launch_igemm(a, nullptr));
+    ensure_zero_page();
+    { Ctx c; std::vector<IgemmArgs> v{a}; run_igemm_group(c, v, dy.p, Cout, ny / Cout, Cout, false, nullptr); }
     dy.get(y, ny);
     API_END
 }
@@ -1198,7 +1260,8 @@ int p3d_op_conv3d_backprop_input(int device, const float* dyh, const float* w, c
     const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
     DevBuf dy(ny, dyh), dw(prod5(ws), w), dx(prod5(xs));
     auto v = igemm_conv_input_side(g, (int)xs[0], dy.p, Cout, Cout, dx.p, Cin, Cin, dw.p, nullptr, nullptr, 0, true);
-    for (auto& a : v) HIPCHECK(p3d_launch_igemm(a, nullptr));
+    ensure_zero_page();
+    { Ctx c; run_igemm_group(c, v, dx.p, Cin, prod5(xs) / Cin, Cin, false, nullptr); }
     dx.get(dxh, prod5(xs));
     API_END
 }
@@ -1230,7 +1293,8 @@ int p3d_op_conv3d_transpose(int device, const float* x, const int64_t xs[5], con
     const int64_t ny = xs[0] * g.I[0] * g.I[1] * g.I[2] * Cout;
     DevBuf dx(prod5(xs), x), dk(prod5(ks), kh), dy(ny), db(Cout, bias);
     auto v = igemm_conv_input_side(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dk.p, bias ? db.p : nullptr, nullptr, 0, true);
-    for (auto& a : v) HIPCHECK(p3d_launch_igemm(a, nullptr));
+    ensure_zero_page();
+    { Ctx c; run_igemm_group(c, v, dy.p, Cout, ny / Cout, Cout, false, nullptr); }
     dy.get(y, ny);
     API_END
 }

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #define P3D_MAX_TAPS 27
+#define P3D_STAT_REPLICAS 16   // per-channel accumulators are replicated to spread same-address atomics
 
 struct P3dTap {
     int16_t dd, dh, dw;   // gathered coordinate = g*is + d{d,h,w}
@@ -38,7 +39,7 @@ struct IgemmArgs {
     const float* w;       // weights: slab widx is [K][Nc] (wT=0) or [Nc][K] (wT=1)
     int wT;
     const float* bias;    // [Nc] or null
-    double* stats;        // [Nc][2] running (sum, sum of squares) of the stored values, or null
+    double* stats;        // [P3D_STAT_REPLICAS][Nc][2] (sum, sum of squares) of the stored values, or null
     int accum;            // 1: Y += result (gradient accumulation)
     int sigmoid;          // 1: store 1/(1+exp(-v)) (unused by the generic path today)
     // stem mode (firstconv1, p3d.py:172): the W axis and the 3 input channels are
@@ -46,8 +47,15 @@ struct IgemmArgs {
     int stem_wfloats;     // Wi*Cin floats per input row (0 = not stem)
     int stem_wstep;       // floats advanced per output column (sw*Cin)
     int stem_wpad;        // floats of left padding (pad_w*Cin)
+    const float* zeros;   // >= 128 B of zeros in device memory (source for padded / tail lanes; igemm2 only)
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
+};
+
+// Tile and split-K choice of the pipelined kernel (conv_igemm2.hip)
+struct P3dIgemmPlan {
+    int bm = 64, bn = 64, splits = 1;
+    const char* name = "";
 };
 
 // Weight-gradient launch: dW[widx][k][n] += sum_m Xg[m+tap, k] * dY[m, n]
@@ -72,6 +80,8 @@ extern "C++" {
 
 hipError_t p3d_launch_igemm(const IgemmArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad(const WgradArgs& a, hipStream_t s);
+P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split);
+hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipStream_t s);
 const char* p3d_igemm_variant(const IgemmArgs& a);     // kernel symbol the launcher will pick
 const char* p3d_wgrad_variant(const WgradArgs& a);
 
@@ -79,13 +89,15 @@ const char* p3d_wgrad_variant(const WgradArgs& a);
 struct BnParams {          // device pointers, all [C]
     const float* gamma; const float* beta;
     float* moving_mean; float* moving_var;
-    double* stats;         // [C][2] sum, sumsq filled by the producer's epilogue
+    double* stats;         // [P3D_STAT_REPLICAS][C][2] sum, sumsq filled by the producer's epilogue
     float* scale; float* shift;      // y_hat = scale*y + shift
     float* mean; float* invstd;      // saved for backward
     int C;
 };
 // use_batch: statistics from `stats` over M rows, else moving stats.  update_moving: momentum 0.99 update.
 hipError_t p3d_bn_finalize(const BnParams& bn, long M, int use_batch, int update_moving, float eps, hipStream_t s);
+// stats[c] += (sum, sum of squares) over the M rows of y (for producers that cannot do it in their epilogue)
+hipError_t p3d_bn_stats(const float* y, int ld, long M, int C, double* stats, hipStream_t s);
 
 // Fused normalise/activate/add passes.  Modes (reference p3d.py lines in brackets):
 //  0: z = relu(bn1(y1))                         [58-59, 88+97, 173-174, 201-202]
@@ -105,7 +117,9 @@ struct BnApplyArgs {
 hipError_t p3d_bn_apply(const BnApplyArgs& a, hipStream_t s);
 
 // Backward of the passes above.  Pass 1 reduces per channel sum(dz') and sum(dz' * xhat) into
-// red1/red2 ([C][2] doubles, zeroed by the caller); pass 2 writes the input gradients.
+// red1/red2 ([P3D_STAT_REPLICAS][C][2] doubles, zeroed by the caller); a finalize pass folds the
+// replicas into coef1/coef2 ([C][2] floats: the two sums / M) and the parameter gradients; pass 2
+// writes the input gradients.
 struct BnBwdArgs {
     int mode;
     long M; int C;
@@ -114,6 +128,7 @@ struct BnBwdArgs {
     const float* y2; int ld2; const float* scale2; const float* shift2; const float* mean2; const float* invstd2;
     const float* gamma1; const float* gamma2;
     double* red1; double* red2;
+    float* coef1; float* coef2;
     float* dgamma1; float* dbeta1; float* dgamma2; float* dbeta2;      // parameter grads (written)
     int batch1, batch2;    // 1: batch statistics were used (full BN backward), 0: inference BN
     float* dy1; int lddy1; int acc1;
@@ -121,6 +136,7 @@ struct BnBwdArgs {
     float drop_scale; float drop_rate; unsigned long long seed;
 };
 hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
+hipError_t p3d_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s);
 hipError_t p3d_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);
 
 // ---- max pool (tf.nn.max_pool3d SAME; p3d.py:177,183,189,195) ---------------------------------

@@ -132,7 +132,8 @@ def test_dropout_statistics():
     s.forward(x, 0.0, False)
     base_eval = s.activation('deconv3_re')
     s.forward(x, 0.5, False)
-    assert np.array_equal(s.activation('deconv3_re'), base_eval)
+    # split-K partial sums are combined with fp32 atomics: run-to-run identical only to ~1e-6
+    assert np.abs(s.activation('deconv3_re') - base_eval).max() < 1e-4
     s.forward(x, 0.0, True)
     base = s.activation('deconv3_re')
     s.forward(x, 0.5, True, seed=11)
@@ -140,5 +141,5 @@ def test_dropout_statistics():
     nz = base != 0
     kept = d[nz] != 0
     assert abs(kept.mean() - 0.5) < 0.02
-    assert np.allclose(d[nz][kept], 2 * base[nz][kept], rtol=1e-6)
+    assert np.abs(d[nz][kept] - 2 * base[nz][kept]).max() < 2e-4
     s.close()
