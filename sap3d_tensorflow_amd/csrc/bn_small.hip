@@ -1,0 +1,212 @@
+// BatchNorm for SMALL tensors (M = B*D*H*W <= 1024 rows: every layer of stage 3 at batch 8) on
+// gfx950: statistics + normalise + ReLU + residual in ONE launch, and the whole backward in ONE
+// launch.  tf.layers.batch_normalization on rank-5 input is per-channel, so a block that owns 8
+// channels needs no other block: it keeps its [M x 8] slab in REGISTERS (<= 8 float4 per thread per
+// tensor), reduces with wave shuffles + a 4-entry LDS exchange, and writes the result.  No atomics,
+// no statistics arena, no finalize launch; variance is the two-pass form TF's tf.nn.moments uses.
+// Modes are those of bn_apply_kernel (p3d_kernels.h); reference p3d.py:56-81,88,114,127,133-134.
+#include "p3d_kernels.h"
+
+namespace {
+
+constexpr int CB = 8;          // channels per block
+constexpr int MAXJ = 8;        // rows per thread (128 row slots x 8 = 1024 rows)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
+__device__ __forceinline__ float4 gate4(float4 g, float4 pre) {
+    return make_float4(pre.x > 0.f ? g.x : 0.f, pre.y > 0.f ? g.y : 0.f, pre.z > 0.f ? g.z : 0.f, pre.w > 0.f ? g.w : 0.f);
+}
+
+// Sum of `v` over all threads of the block that share (threadIdx.x & 1); result broadcast to them.
+__device__ __forceinline__ float4 block_sum(float4 v, float4* xch /*[2][4][2] float4 slots*/, int phase) {
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) {
+        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, par = threadIdx.x & 1;
+    float4* slot = xch + (phase & 1) * 8;
+    if (lane < 2) slot[wave * 2 + par] = v;
+    __syncthreads();
+    return add4(add4(slot[par], slot[2 + par]), add4(slot[4 + par], slot[6 + par]));
+}
+
+__device__ __forceinline__ void bn_moments(const float4 (&v)[MAXJ], int nj, int M, int rowslot, float4* xch, int& phase,
+                                           float4& mean, float4& var) {
+    float4 s = f4(0.f);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+        if (j < nj && rowslot + 128 * j < M) s = add4(s, v[j]);
+    const float invM = 1.f / (float)M;
+    mean = mul4(block_sum(s, xch, phase++), f4(invM));
+    float4 q = f4(0.f);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+        if (j < nj && rowslot + 128 * j < M) { const float4 d = sub4(v[j], mean); q = fma4(d, d, q); }
+    var = mul4(block_sum(q, xch, phase++), f4(invM));
+}
+
+__device__ __forceinline__ void bn_coeffs(const BnParams& bn, int c, bool use_batch, bool update_moving, float eps, bool writer,
+                                          float4& mean, float4& var, float4& scale, float4& shift) {
+    if (!use_batch) { mean = ld4(bn.moving_mean + c); var = ld4(bn.moving_var + c); }
+    const float4 inv = make_float4(1.f / sqrtf(var.x + eps), 1.f / sqrtf(var.y + eps), 1.f / sqrtf(var.z + eps), 1.f / sqrtf(var.w + eps));
+    scale = mul4(ld4(bn.gamma + c), inv);
+    shift = sub4(ld4(bn.beta + c), mul4(mean, scale));
+    if (writer) {
+        st4(bn.scale + c, scale); st4(bn.shift + c, shift); st4(bn.mean + c, mean); st4(bn.invstd + c, inv);
+        if (use_batch && update_moving) {     // moving -= (moving - batch) * (1 - 0.99), biased variance (Appendix A.4)
+            const float4 mm = ld4(bn.moving_mean + c), mv = ld4(bn.moving_var + c);
+            st4(bn.moving_mean + c, sub4(mm, mul4(sub4(mm, mean), f4(1.0f - 0.99f))));
+            st4(bn.moving_var + c, sub4(mv, mul4(sub4(mv, var), f4(1.0f - 0.99f))));
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(BnSmallArgs a) {
+    constexpr bool TWO = (MODE == 2 || MODE == 3);
+    __shared__ float4 xch[16];
+    const int c = blockIdx.x * CB + (threadIdx.x & 1) * 4;
+    const int rowslot = threadIdx.x >> 1;
+    const int nj = (a.M + 127) / 128;
+    float4 v1[MAXJ], v2[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int row = rowslot + 128 * j;
+        v1[j] = f4(0.f); v2[j] = f4(0.f);
+        if (j < nj && row < a.M) {
+            v1[j] = ld4(a.y1 + (long long)row * a.ld1 + c);
+            if (MODE != 0) v2[j] = ld4(a.y2 + (long long)row * a.ld2 + c);
+        }
+    }
+    int phase = 0;
+    float4 mean1 = f4(0.f), var1 = f4(1.f), sc1, sh1, mean2 = f4(0.f), var2 = f4(1.f), sc2 = f4(0.f), sh2 = f4(0.f);
+    if (a.batch1) bn_moments(v1, nj, a.M, rowslot, xch, phase, mean1, var1);
+    bn_coeffs(a.bn1, c, a.batch1, a.update_moving, a.eps, rowslot == 0, mean1, var1, sc1, sh1);
+    if (TWO) {
+        if (a.batch2) bn_moments(v2, nj, a.M, rowslot, xch, phase, mean2, var2);
+        bn_coeffs(a.bn2, c, a.batch2, a.update_moving, a.eps, rowslot == 0, mean2, var2, sc2, sh2);
+    }
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int row = rowslot + 128 * j;
+        if (j < nj && row < a.M) {
+            const float4 v = fma4(sc1, v1[j], sh1);
+            float4 z;
+            if (MODE == 0) z = relu4(v);
+            else if (MODE == 1) z = relu4(add4(v, v2[j]));
+            else if (MODE == 2) z = relu4(add4(v, fma4(sc2, v2[j], sh2)));
+            else if (MODE == 3) z = add4(relu4(v), relu4(fma4(sc2, v2[j], sh2)));
+            else z = add4(v2[j], relu4(v));
+            st4(a.z + (long long)row * a.ldz + c, z);
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(BnSmallArgs a) {
+    constexpr bool TWO = (MODE == 2 || MODE == 3);
+    __shared__ float4 xch[16];
+    const int c = blockIdx.x * CB + (threadIdx.x & 1) * 4;
+    const int rowslot = threadIdx.x >> 1;
+    const int nj = (a.M + 127) / 128;
+    const float4 sc1 = ld4(a.bn1.scale + c), sh1 = ld4(a.bn1.shift + c), m1 = ld4(a.bn1.mean + c), i1 = ld4(a.bn1.invstd + c);
+    float4 sc2 = f4(0.f), sh2 = f4(0.f), m2 = f4(0.f), i2 = f4(0.f);
+    if (TWO) { sc2 = ld4(a.bn2.scale + c); sh2 = ld4(a.bn2.shift + c); m2 = ld4(a.bn2.mean + c); i2 = ld4(a.bn2.invstd + c); }
+    float4 g1[MAXJ], xh1[MAXJ], g2[MAXJ], xh2[MAXJ];
+    float4 s1 = f4(0.f), sx1 = f4(0.f), s2 = f4(0.f), sx2 = f4(0.f);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int row = rowslot + 128 * j;
+        g1[j] = f4(0.f); xh1[j] = f4(0.f); g2[j] = f4(0.f); xh2[j] = f4(0.f);
+        if (j < nj && row < a.M) {
+            const float4 dz = ld4(a.dz + (long long)row * a.lddz + c);
+            const float4 y1 = ld4(a.y1 + (long long)row * a.ld1 + c);
+            const float4 v1 = fma4(sc1, y1, sh1);
+            xh1[j] = mul4(sub4(y1, m1), i1);
+            if (MODE == 0) g1[j] = gate4(dz, v1);
+            else {
+                const float4 y2 = ld4(a.y2 + (long long)row * a.ld2 + c);
+                if (MODE == 1) { g1[j] = gate4(dz, add4(v1, y2)); g2[j] = g1[j]; }
+                else if (MODE == 4) { g1[j] = gate4(dz, v1); g2[j] = dz; }
+                else {
+                    const float4 v2 = fma4(sc2, y2, sh2);
+                    xh2[j] = mul4(sub4(y2, m2), i2);
+                    if (MODE == 2) { g1[j] = gate4(dz, add4(v1, v2)); g2[j] = g1[j]; }
+                    else { g1[j] = gate4(dz, v1); g2[j] = gate4(dz, v2); }
+                }
+            }
+            s1 = add4(s1, g1[j]); sx1 = fma4(g1[j], xh1[j], sx1);
+            if (TWO) { s2 = add4(s2, g2[j]); sx2 = fma4(g2[j], xh2[j], sx2); }
+        }
+    }
+    int phase = 0;
+    s1 = block_sum(s1, xch, phase++);
+    sx1 = block_sum(sx1, xch, phase++);
+    if (TWO) { s2 = block_sum(s2, xch, phase++); sx2 = block_sum(sx2, xch, phase++); }
+    if (rowslot == 0) {
+        st4(a.dbeta1 + c, s1); st4(a.dgamma1 + c, sx1);
+        if (TWO) { st4(a.dbeta2 + c, s2); st4(a.dgamma2 + c, sx2); }
+    }
+    const float invM = 1.f / (float)a.M;
+    const float4 k1 = mul4(ld4(a.bn1.gamma + c), i1);
+    const float4 c1 = mul4(s1, f4(invM)), cx1 = mul4(sx1, f4(invM));
+    float4 k2 = f4(0.f), c2 = f4(0.f), cx2 = f4(0.f);
+    if (TWO) { k2 = mul4(ld4(a.bn2.gamma + c), i2); c2 = mul4(s2, f4(invM)); cx2 = mul4(sx2, f4(invM)); }
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int row = rowslot + 128 * j;
+        if (j < nj && row < a.M) {
+            float4 d = a.batch1 ? mul4(k1, sub4(sub4(g1[j], c1), mul4(xh1[j], cx1))) : mul4(k1, g1[j]);
+            st4(a.dy1 + (long long)row * a.lddy1 + c, d);
+            if (MODE != 0) {
+                float4 e;
+                if (TWO) e = a.batch2 ? mul4(k2, sub4(sub4(g2[j], c2), mul4(xh2[j], cx2))) : mul4(k2, g2[j]);
+                else e = g2[j];
+                float* dst = a.dy2 + (long long)row * a.lddy2 + c;
+                if (a.acc2) e = add4(e, ld4(dst));
+                st4(dst, e);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool p3d_bn_small_ok(long M, int C) { return M <= 128 * MAXJ && (C % CB) == 0; }
+
+hipError_t p3d_bn_small_fwd(const BnSmallArgs& a, hipStream_t s) {
+    if (!p3d_bn_small_ok(a.M, a.C)) return hipErrorInvalidValue;
+    const dim3 g(a.C / CB), b(256);
+    switch (a.mode) {
+        case 0: hipLaunchKernelGGL(bn_small_fwd_kernel<0>, g, b, 0, s, a); break;
+        case 1: hipLaunchKernelGGL(bn_small_fwd_kernel<1>, g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(bn_small_fwd_kernel<2>, g, b, 0, s, a); break;
+        case 3: hipLaunchKernelGGL(bn_small_fwd_kernel<3>, g, b, 0, s, a); break;
+        case 4: hipLaunchKernelGGL(bn_small_fwd_kernel<4>, g, b, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t p3d_bn_small_bwd(const BnSmallArgs& a, hipStream_t s) {
+    if (!p3d_bn_small_ok(a.M, a.C)) return hipErrorInvalidValue;
+    const dim3 g(a.C / CB), b(256);
+    switch (a.mode) {
+        case 0: hipLaunchKernelGGL(bn_small_bwd_kernel<0>, g, b, 0, s, a); break;
+        case 1: hipLaunchKernelGGL(bn_small_bwd_kernel<1>, g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(bn_small_bwd_kernel<2>, g, b, 0, s, a); break;
+        case 3: hipLaunchKernelGGL(bn_small_bwd_kernel<3>, g, b, 0, s, a); break;
+        case 4: hipLaunchKernelGGL(bn_small_bwd_kernel<4>, g, b, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

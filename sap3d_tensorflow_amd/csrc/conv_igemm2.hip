@@ -16,6 +16,7 @@
 //
 // fp32 in / fp32 accumulate: v_mfma_f32_32x32x2_f32, exact fp32 at the fp32 peak (157 TFLOP/s).
 #include "p3d_kernels.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -38,63 +39,108 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Per-lane loader state: the LA rows (8-row pieces) this lane fetches every step, kept in registers
-// (an LDS read here would make hipcc drain the in-flight LDS-DMA first).
-template <int LA>
-struct RowRegs {
-    int base[LA];      // n * Di*Hi*Wi, or -1 for rows past M
-    int dhw[LA];       // (g_d*is_d) << 20 | (g_h*is_h) << 10 | (g_w*is_w)
+// Per-lane loader state, all in registers (an LDS read in the load path would make hipcc drain the
+// in-flight LDS-DMA first).  Row pointers are rebuilt only when the kernel tap changes; within a
+// tap a step just advances 32 floats along the channel run.
+template <int LA, int LB>
+struct LoadState {
+    int base[LA];            // n * Di*Hi*Wi, or -1 for rows past M
+    int dhw[LA];             // (g_d*is_d) << 20 | (g_h*is_h) << 10 | (g_w*is_w)
+    const float* aptr[LA];   // row start for the current tap (+ this lane's 16-byte chunk), null when padded
+    int achunk[LA];          // 4 * logical chunk held by this lane's slot
+    int boff[LB];            // weight element offset of this lane's piece within a tap slab (k0 = 0)
+    int bk[LB];              // WT: 4 * logical chunk; !WT: k row within the step
+    bool bok[LB];            // n inside Nc
+    const float* wt;         // slab of the current tap
+    int t, kc;               // next step to issue: tap index, k-chunk index
+    int issued;              // steps issued so far
 };
 
-// Issue the LDS-DMA of one (tap, k-chunk) step.  a_dst / b_dst are __restrict__ so that, once
-// inlined next to compute_stage, hipcc knows the fragment reads cannot alias the DMA targets and
-// does not put s_waitcnt vmcnt(0) in front of them.
 template <int BM, int BN, bool WT>
-__device__ __forceinline__ void issue_stage(const IgemmArgs& p, float* __restrict__ a_dst, float* __restrict__ b_dst,
-                                            const RowRegs<BM / 32>& rr, int gs, int kchunks, int n0, int wave, int lane) {
+__device__ __forceinline__ void loader_init(const IgemmArgs& p, LoadState<BM / 32, BN / 32>& st, unsigned m0, unsigned M,
+                                            int n0, int wave, int lane, int s_begin, int kchunks) {
     constexpr int LA = BM / 32, LB = BN / 32;
     const int a_slot = lane & 7, a_sub = lane >> 3;
-    const int t = gs / kchunks;
-    const int k0 = (gs - t * kchunks) * BK;
-    const P3dTap tap = p.taps[t];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int piece = i * 4 + wave;                 // 8 rows x 128 B
-        const int r = piece * 8 + a_sub;
-        const int q = a_slot ^ ((r >> 1) & 7);          // logical chunk stored in this lane's slot
-        const int id = (rr.dhw[i] >> 20) + tap.dd, ih = ((rr.dhw[i] >> 10) & 1023) + tap.dh, iw = (rr.dhw[i] & 1023) + tap.dw;
-        const bool ok = rr.base[i] >= 0 && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
-                        (unsigned)iw < (unsigned)p.Wi && (k0 + 4 * q) < p.K;
-        const float* src = ok ? p.x + (((long long)rr.base[i] + ((long long)id * p.Hi + ih) * p.Wi + iw) * p.ldx + k0 + 4 * q)
-                              : p.zeros + 4 * a_slot;
-        glds16(src, a_dst + piece * 8 * BK);
+        const int r = (i * 4 + wave) * 8 + a_sub;
+        const unsigned m = m0 + r;
+        st.base[i] = -1; st.dhw[i] = 0; st.aptr[i] = nullptr;
+        st.achunk[i] = 4 * (a_slot ^ ((r >> 1) & 7));
+        if (m < M) {
+            const unsigned gw = m % (unsigned)p.Gw; unsigned t = m / (unsigned)p.Gw;
+            const unsigned gh = t % (unsigned)p.Gh; t /= (unsigned)p.Gh;
+            const unsigned gd = t % (unsigned)p.Gd; const unsigned n = t / (unsigned)p.Gd;
+            st.base[i] = (int)n * p.Di * p.Hi * p.Wi;
+            st.dhw[i] = (int)(((gd * p.isd) << 20) | ((gh * p.ish) << 10) | (gw * p.isw));
+        }
     }
-    const float* wt = p.w + (long long)tap.widx * p.K * p.Nc;
     if (!WT) {
-        // [k][n] image, rows of BN floats, linear
-        constexpr int LANES_PER_ROW = BN / 4;
-        constexpr int ROWS_PER_PIECE = 64 / LANES_PER_ROW;
+        constexpr int LANES_PER_ROW = BN / 4, ROWS_PER_PIECE = 64 / LANES_PER_ROW;
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const int piece = i * 4 + wave;
-            const int kr = piece * ROWS_PER_PIECE + lane / LANES_PER_ROW;
-            const int nc = (lane % LANES_PER_ROW) * 4;
-            const bool ok = (k0 + kr) < p.K && (n0 + nc) < p.Nc;
-            const float* src = ok ? wt + (long long)(k0 + kr) * p.Nc + n0 + nc : p.zeros + 4 * a_slot;
-            glds16(src, b_dst + piece * 256);
+            const int kr = (i * 4 + wave) * ROWS_PER_PIECE + lane / LANES_PER_ROW;
+            const int nc = n0 + (lane % LANES_PER_ROW) * 4;
+            st.bk[i] = kr; st.bok[i] = nc < p.Nc; st.boff[i] = kr * p.Nc + nc;
         }
     } else {
-        // [n][k] image like A (rows of 32 floats, swizzled)
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const int piece = i * 4 + wave;
-            const int r = piece * 8 + a_sub;
-            const int q = a_slot ^ ((r >> 1) & 7);
-            const bool ok = (n0 + r) < p.Nc && (k0 + 4 * q) < p.K;
-            const float* src = ok ? wt + (long long)(n0 + r) * p.K + k0 + 4 * q : p.zeros + 4 * a_slot;
-            glds16(src, b_dst + piece * 8 * BK);
+            const int r = (i * 4 + wave) * 8 + a_sub;
+            st.bk[i] = 4 * (a_slot ^ ((r >> 1) & 7));
+            st.bok[i] = (n0 + r) < p.Nc;
+            st.boff[i] = (n0 + r) * p.K + st.bk[i];
         }
     }
+    st.t = s_begin / kchunks; st.kc = s_begin - st.t * kchunks; st.issued = 0; st.wt = p.w;
+}
+
+template <int LA, int LB>
+__device__ __forceinline__ void loader_set_tap(const IgemmArgs& p, LoadState<LA, LB>& st) {
+    const P3dTap tap = p.taps[st.t];
+    st.wt = p.w + (long long)tap.widx * p.K * p.Nc;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int id = (st.dhw[i] >> 20) + tap.dd, ih = ((st.dhw[i] >> 10) & 1023) + tap.dh, iw = (st.dhw[i] & 1023) + tap.dw;
+        const bool ok = st.base[i] >= 0 && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
+                        (unsigned)iw < (unsigned)p.Wi;
+        st.aptr[i] = ok ? p.x + ((long long)st.base[i] + ((long long)id * p.Hi + ih) * p.Wi + iw) * p.ldx + st.achunk[i] : nullptr;
+    }
+}
+
+// Issue the LDS-DMA of the next (tap, k-chunk) step -- ALWAYS the same number of loads, so the counted
+// vmcnt never changes; steps past the end of this block's slice fetch the zero page.  a_dst / b_dst are
+// __restrict__ so that, inlined next to compute_stage, hipcc knows the fragment reads cannot alias the DMA
+// targets and does not put s_waitcnt vmcnt(0) in front of them.
+template <int BM, int BN, bool WT>
+__device__ __forceinline__ void issue_stage(const IgemmArgs& p, float* __restrict__ a_dst, float* __restrict__ b_dst,
+                                            LoadState<BM / 32, BN / 32>& st, int nsteps, int kchunks, bool first, int wave,
+                                            int lane) {
+    constexpr int LA = BM / 32, LB = BN / 32;
+    const bool live = st.issued < nsteps;
+    if (live && (first || st.kc == 0)) loader_set_tap(p, st);      // wave-uniform, once per tap
+    const int k0 = st.kc * BK;
+    const float* zp = p.zeros + 4 * (lane & 7);
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const bool ok = live && st.aptr[i] != nullptr && (k0 + st.achunk[i]) < p.K;
+        glds16(ok ? st.aptr[i] + k0 : zp, a_dst + (i * 4 + wave) * 8 * BK);
+    }
+    if (!WT) {
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const bool ok = live && st.bok[i] && (k0 + st.bk[i]) < p.K;
+            glds16(ok ? st.wt + (long long)k0 * p.Nc + st.boff[i] : zp, b_dst + (i * 4 + wave) * 256);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const bool ok = live && st.bok[i] && (k0 + st.bk[i]) < p.K;
+            glds16(ok ? st.wt + k0 + st.boff[i] : zp, b_dst + (i * 4 + wave) * 8 * BK);
+        }
+    }
+    ++st.issued;
+    if (++st.kc == kchunks) { st.kc = 0; ++st.t; }
 }
 
 template <int BM, int BN, bool WT>
@@ -137,17 +183,16 @@ __device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, co
 }
 
 // One pipeline step with COMPILE-TIME stage addresses and restrict-qualified views of the ring.
+// Branch-free: wait for this step's loads, barrier, issue step+2, compute.
 template <int BM, int BN, bool WT>
 __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict__ a_dst, float* __restrict__ b_dst,
                                           const float* __restrict__ a_src, const float* __restrict__ b_src,
-                                          f32x16 (&acc)[BM / 64][BN / 64], const RowRegs<BM / 32>& rr, int step, int nsteps,
-                                          int s_begin, int kchunks, int n0, int wave, int lane, int wm, int wn) {
+                                          f32x16 (&acc)[BM / 64][BN / 64], LoadState<BM / 32, BN / 32>& st, int nsteps,
+                                          int kchunks, int wave, int lane, int wm, int wn) {
     constexpr int LPS = BM / 32 + BN / 32;
-    // loads of `step` have landed for this wave (those of step+1 may still fly) ...
-    if (step + 1 < nsteps) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
-    // ... and, past the barrier, for every wave; every wave is also done reading stage (step-1)%3
-    __builtin_amdgcn_s_barrier();
-    if (step + 2 < nsteps) issue_stage<BM, BN, WT>(p, a_dst, b_dst, rr, s_begin + step + 2, kchunks, n0, wave, lane);
+    wait_vmcnt<LPS>();                 // loads of this step have landed for this wave (next step's may still fly)
+    __builtin_amdgcn_s_barrier();      // ... and for every wave; everyone is also done reading the stage refilled next
+    issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
     compute_stage<BM, BN, WT>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
 }
 
@@ -176,34 +221,18 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     const long long m0 = (long long)(blockIdx.x / NT) * BM;
     const int n0 = nt * BN;
 
-    auto decode = [&](long long m, int& n, int& gd, int& gh, int& gw) {
-        gw = (int)(m % p.Gw); long long t = m / p.Gw;
-        gh = (int)(t % p.Gh); t /= p.Gh;
-        gd = (int)(t % p.Gd); n = (int)(t / p.Gd);
-    };
+    const unsigned Mu = (unsigned)M, m0u = (unsigned)m0;      // launcher guarantees M < 2^31
     for (int r = tid; r < BM; r += 256) {
-        const long long m = m0 + r;
+        const unsigned m = m0u + r;
         long long ro = -1;
-        if (m < M) {
-            int n, gd, gh, gw;
-            decode(m, n, gd, gh, gw);
+        if (m < Mu) {
+            const unsigned gw = m % (unsigned)p.Gw; unsigned t = m / (unsigned)p.Gw;
+            const unsigned gh = t % (unsigned)p.Gh; t /= (unsigned)p.Gh;
+            const unsigned gd = t % (unsigned)p.Gd; const unsigned n = t / (unsigned)p.Gd;
             const int od = gd * p.osd + p.ood, oh = gh * p.osh + p.ooh, ow = gw * p.osw + p.oow;
             ro = ((((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.ldy;
         }
         rowOut[r] = ro;
-    }
-    RowRegs<LA> rr;
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        const int r = (i * 4 + wave) * 8 + (lane >> 3);
-        const long long m = m0 + r;
-        rr.base[i] = -1; rr.dhw[i] = 0;
-        if (m < M) {
-            int n, gd, gh, gw;
-            decode(m, n, gd, gh, gw);
-            rr.base[i] = n * p.Di * p.Hi * p.Wi;
-            rr.dhw[i] = ((gd * p.isd) << 20) | ((gh * p.ish) << 10) | (gw * p.isw);
-        }
     }
 
     // ---- this block's slice of the (tap, k-chunk) steps --------------------------------------------
@@ -213,7 +242,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     const int per = (total_steps + nsplit - 1) / nsplit;
     const int s_begin = blockIdx.y * per;
     const int s_end = min(total_steps, s_begin + per);
-    const int nsteps = s_end - s_begin;
+    const int nsteps = max(s_end - s_begin, 0);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -223,16 +252,16 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    LoadState<LA, BN / 32> st;
+    loader_init<BM, BN, WT>(p, st, m0u, Mu, n0, wave, lane, s_begin, kchunks);
     float* A0 = As; float* A1 = As + A_STAGE; float* A2 = As + 2 * A_STAGE;
     float* B0 = Bs; float* B1 = Bs + B_STAGE; float* B2 = Bs + 2 * B_STAGE;
-    if (nsteps > 0) issue_stage<BM, BN, WT>(p, A0, B0, rr, s_begin, kchunks, n0, wave, lane);
-    if (nsteps > 1) issue_stage<BM, BN, WT>(p, A1, B1, rr, s_begin + 1, kchunks, n0, wave, lane);
+    issue_stage<BM, BN, WT>(p, A0, B0, st, nsteps, kchunks, true, wave, lane);
+    issue_stage<BM, BN, WT>(p, A1, B1, st, nsteps, kchunks, false, wave, lane);
     for (int base = 0; base < nsteps; base += STAGES) {
-        pipe_step<BM, BN, WT>(p, A2, B2, A0, B0, acc, rr, base, nsteps, s_begin, kchunks, n0, wave, lane, wm, wn);
-        if (base + 1 < nsteps)
-            pipe_step<BM, BN, WT>(p, A0, B0, A1, B1, acc, rr, base + 1, nsteps, s_begin, kchunks, n0, wave, lane, wm, wn);
-        if (base + 2 < nsteps)
-            pipe_step<BM, BN, WT>(p, A1, B1, A2, B2, acc, rr, base + 2, nsteps, s_begin, kchunks, n0, wave, lane, wm, wn);
+        pipe_step<BM, BN, WT>(p, A2, B2, A0, B0, acc, st, nsteps, kchunks, wave, lane, wm, wn);
+        if (base + 1 < nsteps) pipe_step<BM, BN, WT>(p, A0, B0, A1, B1, acc, st, nsteps, kchunks, wave, lane, wm, wn);
+        if (base + 2 < nsteps) pipe_step<BM, BN, WT>(p, A1, B1, A2, B2, acc, st, nsteps, kchunks, wave, lane, wm, wn);
     }
     __syncthreads();      // rowOut written above is read below (also when nsteps == 0)
 
@@ -324,15 +353,26 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split) {
     else if (tiles(128, 64) >= want || (a.Nc <= 64 && tiles(128, 64) >= 128)) { pl.bm = 128; pl.bn = 64; }
     else { pl.bm = 64; pl.bn = 64; }
     pl.splits = 1;
-    if (allow_split && steps >= 4) {
+    if (allow_split && steps >= 8) {
+        // measured on MI355X (scratch/tune_igemm.py, stage-2/3 shapes at batch 8): slicing pays below ~150
+        // tiles; ~300 blocks in total and >= 6 steps per slice is the sweet spot, beyond that the fp32
+        // atomics of the partial tiles cost more than the extra CUs bring.
         const long long t = tiles(pl.bm, pl.bn);
-        if (t < want) {
-            long long s = (want + t - 1) / t;
-            const long long smax = steps / 2;          // at least 2 steps per slice
+        if (t < 150) {
+            long long s = (300 + t / 2) / t;
+            const long long smax = steps / 6 > 0 ? steps / 6 : 1;
             if (s > smax) s = smax;
             if (s < 1) s = 1;
             pl.splits = (int)s;
         }
+    }
+    if (const char* e = getenv("P3D_SPLITS")) {            // tuning override (scratch/tune_igemm.py)
+        const int v = atoi(e);
+        if (v >= 1 && allow_split && v <= steps) pl.splits = v;
+    }
+    if (const char* e = getenv("P3D_TILE")) {
+        const int v = atoi(e);
+        if (v == 0) { pl.bm = 64; pl.bn = 64; } else if (v == 1) { pl.bm = 128; pl.bn = 64; } else if (v == 2) { pl.bm = 128; pl.bn = 128; }
     }
     pl.name = pl.bm == 128 ? (pl.bn == 128 ? "igemm2_kernel<128,128>" : "igemm2_kernel<128,64>") : "igemm2_kernel<64,64>";
     return pl;
@@ -341,6 +381,8 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split) {
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& pl, hipStream_t s) {
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     if (M <= 0 || a.Nc <= 0) return hipSuccess;
+    if (M >= (1ll << 31) || (long long)a.N * a.Di * a.Hi * a.Wi >= (1ll << 31)) return hipErrorInvalidValue;
+    if (a.Gd * a.isd >= 1024 || a.Gh * a.ish >= 1024 || a.Gw * a.isw >= 1024) return hipErrorInvalidValue;   // packed coords
     if (a.ntaps > P3D_MAX_TAPS || a.stem_wfloats) return hipErrorInvalidValue;
     if ((a.K & 3) || (a.ldx & 3) || !a.zeros) return hipErrorInvalidValue;
     if (!a.wT && (a.Nc & 3)) return hipErrorInvalidValue;

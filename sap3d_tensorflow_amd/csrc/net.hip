@@ -98,10 +98,15 @@ struct Ctx {
     bool update_moving = false;
     hipStream_t s = nullptr;
     Prof* prof = nullptr;
+    // planning pass (finalize_build): nothing is launched, zero-fill requests are recorded instead
+    std::vector<std::pair<float*, size_t>>* dry = nullptr;
+    // buffers inside [z0, z1) are zeroed wholesale at the start of the phase: no per-op memset
+    const char* z0 = nullptr; const char* z1 = nullptr;
 };
 
 template <typename F>
 void launch(const Ctx& c, const char* kernel, double flops, double bytes, F&& f) {
+    if (c.dry) return;
     if (!c.prof) {
         HIPCHECK(f());
         return;
@@ -139,7 +144,7 @@ void launch_igemm(const Ctx& c, const IgemmArgs& a0, int allow_split = 0) {
     launch(c, pl.name, fl, by, [&]() { return p3d_launch_igemm2(a, pl, c.s); });
 }
 
-void zero_strided(float* p, int ld, int64_t rows, int C, hipStream_t s);
+void zero_strided(const Ctx& c, float* p, int ld, int64_t rows, int C);
 
 // A group of implicit-GEMM launches that together produce one output tensor (one conv forward,
 // or the residue classes of an input gradient / transposed conv).  Lets small problems slice K
@@ -158,7 +163,7 @@ void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld
         for (auto& a : v) { a.accum = accumulate ? 1 : 0; a.stats = stats; launch_igemm(c, a, 0); }
         return;
     }
-    if (!accumulate) zero_strided(out, ld, rows, C, c.s);
+    if (!accumulate) zero_strided(c, out, ld, rows, C);
     for (auto& a : v) {
         a.stats = nullptr;
         IgemmArgs t = a;
@@ -171,12 +176,18 @@ void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld
         launch(c, "bn_stats_kernel", 0, 4.0 * rows * C, [&]() { return p3d_bn_stats(out, ld, rows, C, stats, c.s); });
 }
 
-void launch_wgrad(const Ctx& c, const WgradArgs& a) {
+void launch_wgrad(const Ctx& c, const WgradArgs& a0) {
+    WgradArgs a = a0;
     const double M = (double)a.N * a.Gd * a.Gh * a.Gw;
     const double side = (double)a.N * a.Di * a.Hi * a.Wi;
-    launch(c, p3d_wgrad_variant(a), 2.0 * M * a.ntaps * (double)a.K * a.Nc,
-           4.0 * (std::min(M * a.ntaps, side) * a.K + M * a.Nc + (double)a.ntaps * a.K * a.Nc),
-           [&]() { return p3d_launch_wgrad(a, c.s); });
+    const double fl = 2.0 * M * a.ntaps * (double)a.K * a.Nc;
+    const double by = 4.0 * (std::min(M * a.ntaps, side) * a.K + M * a.Nc + (double)a.ntaps * a.K * a.Nc);
+    if (a.stem_wfloats) {
+        launch(c, p3d_wgrad_variant(a), fl, by, [&]() { return p3d_launch_wgrad(a, c.s); });
+        return;
+    }
+    a.zeros = g_zero_page;
+    launch(c, p3d_wgrad2_variant(a), fl, by, [&]() { return p3d_launch_wgrad2(a, c.s); });
 }
 
 struct Op {
@@ -324,9 +335,14 @@ WgradArgs wgrad_conv(const ConvGeo& g, int N, const float* x, int ldx, int Cin, 
     return a;
 }
 
-void zero_strided(float* p, int ld, int64_t rows, int C, hipStream_t s) {
-    if (ld == C) HIPCHECK(hipMemsetAsync(p, 0, (size_t)rows * C * sizeof(float), s));
-    else HIPCHECK(hipMemset2DAsync(p, (size_t)ld * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)rows, s));
+void zero_strided(const Ctx& c, float* p, int ld, int64_t rows, int C) {
+    if (c.dry) {
+        if (ld == C) c.dry->push_back({p, (size_t)rows * C * sizeof(float)});      // dense buffers may move into the arena
+        return;
+    }
+    if ((const char*)p >= c.z0 && (const char*)p < c.z1) return;                    // zeroed with the arena
+    if (ld == C) HIPCHECK(hipMemsetAsync(p, 0, (size_t)rows * C * sizeof(float), c.s));
+    else HIPCHECK(hipMemset2DAsync(p, (size_t)ld * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)rows, c.s));
 }
 
 }  // namespace
@@ -366,6 +382,8 @@ struct p3d_handle {
     std::vector<std::function<void()>> late_bind;                // pointer fix-ups after arenas are allocated
 
     std::vector<Op> ops;
+    char *zf = nullptr, *zb = nullptr;          // zero arenas: split-K outputs (forward) / gradients (backward)
+    size_t zf_bytes = 0, zb_bytes = 0;
     Act* x_in = nullptr;
     Act* pred = nullptr;
     Act* logits = nullptr;
@@ -463,6 +481,9 @@ struct p3d_handle {
         return bn;
     }
     double* bn_stats(BN* bn) { return stats_arena + bn->stats_off; }
+    // Producers of tensors that the one-launch small-tensor BN will consume need no statistics epilogue.
+    static bool bn_is_small(int64_t rows, int C, bool dropout = false) { return !dropout && p3d_bn_small_ok((long)rows, C); }
+    BN* stats_target(BN* bn, int64_t rows, int C, bool dropout = false) { return bn_is_small(rows, C, dropout) ? nullptr : bn; }
     BnParams bn_params(BN* bn) {
         BnParams b;
         b.gamma = bn->gamma->p; b.beta = bn->beta->p; b.moving_mean = bn->mm->p; b.moving_var = bn->mv->p;
@@ -490,7 +511,8 @@ struct p3d_handle {
         op.fwd = [=](const Ctx& c) {
             std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
                                                         nullptr, 0, stem)};
-            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, bn ? bn_stats(bn) : nullptr);
+            BN* sbn = bn ? stats_target(bn, y->rows(), Cout) : nullptr;
+            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? bn_stats(sbn) : nullptr);
         };
         op.bwd = [=](const Ctx& c) {
             WgradArgs wa = wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr, stem);
@@ -508,7 +530,7 @@ struct p3d_handle {
 
     // tf.layers.conv3d_transpose(x, filters, k, s, 'same'): kernel [kd,kh,kw,Cout,Cin].
     Act* deconv(const std::string& opname, Act* x, Param* kern, Param* bias, const int k[3], const int s[3], int Cout, BN* bn,
-                const std::string& out_name) {
+                const std::string& out_name, bool bn_has_dropout = false) {
         const ConvGeo g = make_geo(x->D * s[0], x->H * s[1], x->W * s[2], k, s);    // conv whose input is y
         Act* y = new_act(out_name, x->N, g.I[0], g.I[1], g.I[2], Cout);
         char* xflag = x->g ? consume(x) : nullptr;
@@ -524,7 +546,8 @@ struct p3d_handle {
         op.fwd = [=](const Ctx& c) {
             auto v = igemm_conv_input_side(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, kern->p, bias ? bias->p : nullptr,
                                            nullptr, 0, true);
-            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, bn ? bn_stats(bn) : nullptr);
+            BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
+            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? bn_stats(sbn) : nullptr);
         };
         op.bwd = [=](const Ctx& c) {
             // dK[tap][co][ci] = sum dy_big[o][co] * x[i][ci]  (conv wgrad with the roles of x and dy swapped)
@@ -566,7 +589,35 @@ struct p3d_handle {
         op.bflops = 0; op.bbytes = tens * (y2 ? 7 : 5);
         op.first_param_off = bn1->gamma->off;
         if (two && bn2->gamma->off < op.first_param_off) op.first_param_off = bn2->gamma->off;
+        const bool small = bn_is_small(M, C, dropout);
+        auto small_args = [=](const Ctx& c) {
+            BnSmallArgs a;
+            memset(&a, 0, sizeof(a));
+            a.mode = mode; a.M = (int)M; a.C = C;
+            a.y1 = y1->p; a.ld1 = y1->ld;
+            if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; }
+            a.bn1 = bn_params(bn1);
+            if (two) a.bn2 = bn_params(bn2);
+            a.update_moving = c.update_moving; a.eps = 1e-3f;
+            a.z = out->p; a.ldz = out->ld;
+            a.dz = out->g; a.lddz = out->ld;
+            a.dy1 = y1->g; a.lddy1 = y1->ld;
+            if (y2) { a.dy2 = y2->g; a.lddy2 = y2->ld; a.acc2 = *f2; }
+            a.dgamma1 = bn1->gamma->g; a.dbeta1 = bn1->beta->g;
+            if (two) { a.dgamma2 = bn2->gamma->g; a.dbeta2 = bn2->beta->g; }
+            return a;
+        };
+        const std::string kn_sf = "bn_small_fwd_kernel<" + std::to_string(mode) + ">";
+        const std::string kn_sb = "bn_small_bwd_kernel<" + std::to_string(mode) + ">";
         op.fwd = [=](const Ctx& c) {
+            if (small) {
+                bn1->used_batch = bn1->follows_flag ? c.training : true;
+                if (two) bn2->used_batch = bn2->follows_flag ? c.training : true;
+                BnSmallArgs a = small_args(c);
+                a.batch1 = bn1->used_batch; a.batch2 = two ? bn2->used_batch : 0;
+                launch(c, kn_sf.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_small_fwd(a, c.s); });
+                return;
+            }
             auto fin = [&](BN* bn) {
                 bn->used_batch = bn->follows_flag ? c.training : true;
                 launch(c, "bn_finalize_kernel", 0, 64.0 * bn->C, [&]() {
@@ -586,6 +637,12 @@ struct p3d_handle {
             launch(c, kn_apply.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_apply(a, c.s); });
         };
         op.bwd = [=](const Ctx& c) {
+            if (small) {
+                BnSmallArgs sa = small_args(c);
+                sa.batch1 = bn1->used_batch; sa.batch2 = two ? bn2->used_batch : 0;
+                launch(c, kn_sb.c_str(), 0, tens * (y2 ? 5 : 3), [&]() { return p3d_bn_small_bwd(sa, c.s); });
+                return;
+            }
             BnBwdArgs a;
             memset(&a, 0, sizeof(a));
             a.mode = mode; a.M = M; a.C = C;
@@ -633,7 +690,7 @@ struct p3d_handle {
         const double pool_bytes = op.bytes;
         op.fwd = [=](const Ctx& c) { launch(c, "maxpool_fwd_kernel", 0, pool_bytes, [&]() { return p3d_maxpool_fwd(mk(), c.s); }); };
         op.bwd = [=](const Ctx& c) {
-            if (!*xflag) zero_strided(x->g, x->ld, x->rows(), x->C, c.s);
+            if (!*xflag) zero_strided(c, x->g, x->ld, x->rows(), x->C);
             launch(c, "maxpool_bwd_kernel", 0, pool_bytes * 2, [&]() { return p3d_maxpool_bwd(mk(), c.s); });
         };
         ops.push_back(op);
@@ -756,7 +813,7 @@ struct p3d_handle {
             Param* k = conv_weight("conv3d_transpose_2/kernel", {3, 3, 3, 2 * b, 8 * b});
             Param* bi = add_param("conv3d_transpose_2/bias", {2 * b}, true, INIT_ZEROS);
             BN* bn = add_bn("deconv3_bn", 2 * b, true);
-            Act* y = deconv("deconv3", cat2, k, bi, k333, s222, 2 * b, bn, "");
+            Act* y = deconv("deconv3", cat2, k, bi, k333, s222, 2 * b, bn, "", /*bn_has_dropout=*/true);
             d3 = bn_apply("deconv3_bn", 0, y, bn, nullptr, nullptr, nullptr, "deconv3_re", /*dropout=*/true);
         }
         Param* k4 = conv_weight("conv3d/kernel", {1, 1, 1, 2 * b, b / 2});
@@ -815,6 +872,41 @@ struct p3d_handle {
         bnbuf = dalloc<float>(bnbuf_count);
         for (auto& f : late_bind) f();
         late_bind.clear();
+        plan_zero_arenas();
+    }
+
+    // Dry-run forward and backward once: every dense buffer an op would zero-fill before adding into it
+    // (split-K outputs, atomically scattered gradients) is moved into one contiguous arena per phase, so a
+    // step issues two memsets instead of a few hundred.
+    void plan_zero_arenas() {
+        for (int phase = 0; phase < 2; ++phase) {
+            std::vector<std::pair<float*, size_t>> reqs;
+            Ctx c; c.training = true; c.s = stream; c.dry = &reqs;
+            if (phase == 0) { for (auto& op : ops) op.fwd(c); }
+            else { for (int i = (int)ops.size() - 1; i >= 0; --i) ops[i].bwd(c); }
+            std::vector<std::pair<Act*, bool>> movers;     // (act, is_grad)
+            size_t total = 0;
+            for (auto& rq : reqs)
+                for (auto& a : acts) {
+                    if (a.parent || !a.views.empty()) continue;
+                    const size_t bytes = (size_t)a.rows() * a.C * sizeof(float);
+                    if (bytes != rq.second) continue;
+                    const bool is_g = (a.g == rq.first), is_p = (a.p == rq.first);
+                    if (!is_g && !is_p) continue;
+                    movers.push_back({&a, is_g});
+                    total += (bytes + 255) / 256 * 256;
+                    break;
+                }
+            if (!total) continue;
+            char* base = (char*)dalloc<char>((int64_t)total);
+            size_t off = 0;
+            for (auto& mv : movers) {
+                float*& ptr = mv.second ? mv.first->g : mv.first->p;
+                ptr = (float*)(base + off);                 // the old allocation stays owned by `allocs`
+                off += ((size_t)mv.first->rows() * mv.first->C * sizeof(float) + 255) / 256 * 256;
+            }
+            if (phase == 0) { zf = base; zf_bytes = total; } else { zb = base; zb_bytes = total; }
+        }
     }
 
     // ---- execution -------------------------------------------------------------------------------
@@ -830,9 +922,12 @@ struct p3d_handle {
     }
     void run_forward(const Ctx& c) {
         HIPCHECK(hipMemsetAsync(stats_arena, 0, (size_t)stats_count * sizeof(double), c.s));
+        if (zf_bytes) HIPCHECK(hipMemsetAsync(zf, 0, zf_bytes, c.s));
+        Ctx cz = c; cz.z0 = zf; cz.z1 = zf + zf_bytes;
+        const Ctx& c2 = cz;
         for (auto& op : ops) {
             if (c.prof) c.prof->cur_op = op.name;
-            op.fwd(c);
+            op.fwd(c2);
             debug_sync("fwd", op, c);
         }
     }
@@ -840,7 +935,9 @@ struct p3d_handle {
         HIPCHECK(hipMemsetAsync(d_loss, 0, sizeof(double), c.s));
         launch(c, "smooth_l1_kernel", 0, 12.0 * pred->rows(), [&]() { return p3d_smooth_l1(pred->p, d_y, pred->rows(), d_loss, d_dlogits, 1, c.s); });
     }
-    void run_backward(const Ctx& c, bool allreduce) {
+    void run_backward(const Ctx& c0, bool allreduce) {
+        Ctx c = c0; c.z0 = zb; c.z1 = zb + zb_bytes;
+        if (zb_bytes) HIPCHECK(hipMemsetAsync(zb, 0, zb_bytes, c.s));
         HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
         HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), c.s));
         int64_t hi = n_train;                        // grads in [hi, n_train) are already handed to the comm stream
@@ -1276,7 +1373,8 @@ int p3d_op_conv3d_backprop_filter(int device, const float* x, const int64_t xs[5
     const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
     DevBuf dx(prod5(xs), x), dy(ny, dyh), dw(prod5(ws)), db(Cout);
     WgradArgs a = wgrad_conv(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, dbh ? db.p : nullptr, is_stem_shape(xs, ws));
-    HIPCHECK(p3d_launch_wgrad(a, nullptr));
+    ensure_zero_page();
+    { Ctx c; launch_wgrad(c, a); }
     dw.get(dwh, prod5(ws));
     if (dbh) db.get(dbh, Cout);
     API_END

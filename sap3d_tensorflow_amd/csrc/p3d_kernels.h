@@ -70,6 +70,7 @@ struct WgradArgs {
     float* dbias;         // [Nc] or null (column sums of dy, added by tap 0 / k-tile 0 blocks)
     int ksplit;           // number of M-range splits (gridDim.y)
     int stem_wfloats, stem_wstep, stem_wpad;
+    const float* zeros;   // zero page (wgrad2 only)
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
 };
@@ -84,6 +85,8 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split);
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipStream_t s);
 const char* p3d_igemm_variant(const IgemmArgs& a);     // kernel symbol the launcher will pick
 const char* p3d_wgrad_variant(const WgradArgs& a);
+hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s);
+const char* p3d_wgrad2_variant(const WgradArgs& a);
 
 // ---- BatchNorm (tf.layers.batch_normalization, rank-5, eps 1e-3) ------------------------------
 struct BnParams {          // device pointers, all [C]
@@ -138,6 +141,24 @@ struct BnBwdArgs {
 hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
 hipError_t p3d_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s);
 hipError_t p3d_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);
+
+// Small-tensor BatchNorm (bn_small.hip): one launch forward, one launch backward, M <= 1024 rows.
+struct BnSmallArgs {
+    int mode; int M; int C;
+    const float* y1; int ld1;
+    const float* y2; int ld2;           // second BN input (modes 2,3) or residual (modes 1,4)
+    BnParams bn1, bn2;
+    int batch1, batch2;                 // 1: batch statistics, 0: moving statistics
+    int update_moving; float eps;
+    float* z; int ldz;
+    const float* dz; int lddz;          // backward
+    float* dy1; int lddy1;
+    float* dy2; int lddy2; int acc2;
+    float* dgamma1; float* dbeta1; float* dgamma2; float* dbeta2;
+};
+bool p3d_bn_small_ok(long M, int C);
+hipError_t p3d_bn_small_fwd(const BnSmallArgs& a, hipStream_t s);
+hipError_t p3d_bn_small_bwd(const BnSmallArgs& a, hipStream_t s);
 
 // ---- max pool (tf.nn.max_pool3d SAME; p3d.py:177,183,189,195) ---------------------------------
 struct PoolArgs {
