@@ -23,7 +23,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BK = 32;
-constexpr int STAGES = 3;
+template <int BM, int BN>
+struct Ring { static constexpr int stages = (BM >= 128) ? 2 : 3; };
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
     // LDS destination = wave-uniform base + lane * 16 B
@@ -190,7 +191,8 @@ __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict_
                                           f32x16 (&acc)[BM / 64][BN / 64], LoadState<BM / 32, BN / 32>& st, int nsteps,
                                           int kchunks, int wave, int lane, int wm, int wn) {
     constexpr int LPS = BM / 32 + BN / 32;
-    wait_vmcnt<LPS>();                 // loads of this step have landed for this wave (next step's may still fly)
+    // loads of this step have landed for this wave; with a 3-stage ring the next step's may still fly
+    wait_vmcnt<(Ring<BM, BN>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();      // ... and for every wave; everyone is also done reading the stage refilled next
     issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
     compute_stage<BM, BN, WT>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     constexpr int LA = BM / 32;                 // A glds per wave per step
     constexpr int A_STAGE = BM * BK;            // floats
     constexpr int B_STAGE = BK * BN;
+    constexpr int STAGES = Ring<BM, BN>::stages;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);
@@ -254,14 +257,24 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
 
     LoadState<LA, BN / 32> st;
     loader_init<BM, BN, WT>(p, st, m0u, Mu, n0, wave, lane, s_begin, kchunks);
-    float* A0 = As; float* A1 = As + A_STAGE; float* A2 = As + 2 * A_STAGE;
-    float* B0 = Bs; float* B1 = Bs + B_STAGE; float* B2 = Bs + 2 * B_STAGE;
-    issue_stage<BM, BN, WT>(p, A0, B0, st, nsteps, kchunks, true, wave, lane);
-    issue_stage<BM, BN, WT>(p, A1, B1, st, nsteps, kchunks, false, wave, lane);
-    for (int base = 0; base < nsteps; base += STAGES) {
-        pipe_step<BM, BN, WT>(p, A2, B2, A0, B0, acc, st, nsteps, kchunks, wave, lane, wm, wn);
-        if (base + 1 < nsteps) pipe_step<BM, BN, WT>(p, A0, B0, A1, B1, acc, st, nsteps, kchunks, wave, lane, wm, wn);
-        if (base + 2 < nsteps) pipe_step<BM, BN, WT>(p, A1, B1, A2, B2, acc, st, nsteps, kchunks, wave, lane, wm, wn);
+    if (STAGES == 3) {
+        float* A0 = As; float* A1 = As + A_STAGE; float* A2 = As + 2 * A_STAGE;
+        float* B0 = Bs; float* B1 = Bs + B_STAGE; float* B2 = Bs + 2 * B_STAGE;
+        issue_stage<BM, BN, WT>(p, A0, B0, st, nsteps, kchunks, true, wave, lane);
+        issue_stage<BM, BN, WT>(p, A1, B1, st, nsteps, kchunks, false, wave, lane);
+        for (int base = 0; base < nsteps; base += 3) {
+            pipe_step<BM, BN, WT>(p, A2, B2, A0, B0, acc, st, nsteps, kchunks, wave, lane, wm, wn);
+            if (base + 1 < nsteps) pipe_step<BM, BN, WT>(p, A0, B0, A1, B1, acc, st, nsteps, kchunks, wave, lane, wm, wn);
+            if (base + 2 < nsteps) pipe_step<BM, BN, WT>(p, A1, B1, A2, B2, acc, st, nsteps, kchunks, wave, lane, wm, wn);
+        }
+    } else {
+        float* A0 = As; float* A1 = As + A_STAGE;
+        float* B0 = Bs; float* B1 = Bs + B_STAGE;
+        issue_stage<BM, BN, WT>(p, A0, B0, st, nsteps, kchunks, true, wave, lane);
+        for (int base = 0; base < nsteps; base += 2) {
+            pipe_step<BM, BN, WT>(p, A1, B1, A0, B0, acc, st, nsteps, kchunks, wave, lane, wm, wn);
+            if (base + 1 < nsteps) pipe_step<BM, BN, WT>(p, A0, B0, A1, B1, acc, st, nsteps, kchunks, wave, lane, wm, wn);
+        }
     }
     __syncthreads();      // rowOut written above is read below (also when nsteps == 0)
 
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
 
 template <int BM, int BN>
 constexpr size_t smem_bytes() {
-    return (size_t)STAGES * (BM * BK + BK * BN) * 4 + BM * 8 + 2 * BN * 2 * 4;
+    return (size_t)Ring<BM, BN>::stages * (BM * BK + BK * BN) * 4 + BM * 8 + 2 * BN * 2 * 4;
 }
 
 template <int BM, int BN>

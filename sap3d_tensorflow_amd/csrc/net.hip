@@ -98,6 +98,7 @@ struct Ctx {
     bool update_moving = false;
     hipStream_t s = nullptr;
     Prof* prof = nullptr;
+    hipStream_t side = nullptr;       // weight gradients run here, off the backward critical path
     // planning pass (finalize_build): nothing is launched, zero-fill requests are recorded instead
     std::vector<std::pair<float*, size_t>>* dry = nullptr;
     // buffers inside [z0, z1) are zeroed wholesale at the start of the phase: no per-op memset
@@ -174,6 +175,17 @@ void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld
     }
     if (stats)
         launch(c, "bn_stats_kernel", 0, 4.0 * rows * C, [&]() { return p3d_bn_stats(out, ld, rows, C, stats, c.s); });
+}
+
+// Runs `f(side_ctx)` on the side stream after everything queued so far on the main stream.
+template <typename F>
+void on_side_stream(const Ctx& c, hipEvent_t ev, F&& f) {
+    if (c.dry || !c.side || !ev) { f(c); return; }
+    HIPCHECK(hipEventRecord(ev, c.s));
+    HIPCHECK(hipStreamWaitEvent(c.side, ev, 0));
+    Ctx sc = c;
+    sc.s = c.side;
+    f(sc);
 }
 
 void launch_wgrad(const Ctx& c, const WgradArgs& a0) {
@@ -361,7 +373,15 @@ void ensure_zero_page() {
 // ==================================================================================================
 struct p3d_handle {
     p3d_config cfg;
-    hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipStream_t stream = nullptr, comm_stream = nullptr, side_stream = nullptr;
+    std::vector<hipEvent_t> fork_events;
+    hipEvent_t ev_side_done = nullptr, ev_side_bucket = nullptr;
+    hipEvent_t new_fork_event() {
+        hipEvent_t e = nullptr;
+        HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        fork_events.push_back(e);
+        return e;
+    }
     std::vector<void*> allocs;
 
     std::deque<Param> params;                 // stable addresses
@@ -508,6 +528,7 @@ struct p3d_handle {
         op.bflops = op.flops * (x->g ? 2 : 1);
         op.bbytes = op.bytes * (x->g ? 2 : 1);
         op.first_param_off = w->off;
+        hipEvent_t fork_ev = new_fork_event();
         op.fwd = [=](const Ctx& c) {
             std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
                                                         nullptr, 0, stem)};
@@ -515,8 +536,10 @@ struct p3d_handle {
             run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? bn_stats(sbn) : nullptr);
         };
         op.bwd = [=](const Ctx& c) {
-            WgradArgs wa = wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr, stem);
-            launch_wgrad(c, wa);
+            on_side_stream(c, fork_ev, [&](const Ctx& sc) {
+                WgradArgs wa = wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr, stem);
+                launch_wgrad(sc, wa);
+            });
             if (xflag) {
                 const int accum = *xflag;
                 auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, w->p, nullptr, nullptr, accum,
@@ -543,6 +566,7 @@ struct p3d_handle {
         op.bytes = 4.0 * (x->rows() * (double)Cin + y->rows() * (double)Cout + (double)k[0] * k[1] * k[2] * Cin * Cout);
         op.bflops = 2 * op.flops; op.bbytes = 2 * op.bytes;
         op.first_param_off = kern->off;
+        hipEvent_t fork_ev = new_fork_event();
         op.fwd = [=](const Ctx& c) {
             auto v = igemm_conv_input_side(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, kern->p, bias ? bias->p : nullptr,
                                            nullptr, 0, true);
@@ -551,10 +575,12 @@ struct p3d_handle {
         };
         op.bwd = [=](const Ctx& c) {
             // dK[tap][co][ci] = sum dy_big[o][co] * x[i][ci]  (conv wgrad with the roles of x and dy swapped)
-            WgradArgs wa = wgrad_conv(g, x->N, y->g, y->ld, Cout, x->p, x->ld, Cin, kern->g, nullptr);
-            launch_wgrad(c, wa);
-            if (bias)
-                launch(c, "colsum_kernel", 0, 4.0 * y->rows() * Cout, [&]() { return p3d_colsum(y->g, y->ld, y->rows(), Cout, bias->g, c.s); });
+            on_side_stream(c, fork_ev, [&](const Ctx& sc) {
+                WgradArgs wa = wgrad_conv(g, x->N, y->g, y->ld, Cout, x->p, x->ld, Cin, kern->g, nullptr);
+                launch_wgrad(sc, wa);
+                if (bias)
+                    launch(sc, "colsum_kernel", 0, 4.0 * y->rows() * Cout, [&]() { return p3d_colsum(y->g, y->ld, y->rows(), Cout, bias->g, sc.s); });
+            });
             if (xflag) {
                 std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, kern->p, nullptr, nullptr, *xflag)};
                 run_igemm_group(c, v, x->g, x->ld, x->rows(), Cin, *xflag != 0, nullptr);
@@ -937,6 +963,8 @@ struct p3d_handle {
     }
     void run_backward(const Ctx& c0, bool allreduce) {
         Ctx c = c0; c.z0 = zb; c.z1 = zb + zb_bytes;
+        static const bool no_side = getenv("P3D_NO_SIDE_STREAM") != nullptr;
+        c.side = (c.prof || no_side) ? nullptr : side_stream;      // per-launch profiling keeps one stream
         if (zb_bytes) HIPCHECK(hipMemsetAsync(zb, 0, zb_bytes, c.s));
         HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
         HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), c.s));
@@ -950,20 +978,28 @@ struct p3d_handle {
                 const int64_t lo = ops[i].first_param_off;
                 if (hi - lo >= bucket_floats || i == 0) {
                     const int64_t start = (i == 0) ? 0 : lo;
-                    if (hi > start) reduce_range(start, hi, c.s);
+                    if (hi > start) reduce_range(start, hi, c);
                     hi = start;
                 }
             }
         }
+        if (c.side) {       // weight gradients must be complete before the optimiser (and the next step)
+            HIPCHECK(hipEventRecord(ev_side_done, c.side));
+            HIPCHECK(hipStreamWaitEvent(c.s, ev_side_done, 0));
+        }
         if (allreduce && comm) {
-            if (hi > 0) reduce_range(0, hi, c.s);
+            if (hi > 0) reduce_range(0, hi, c);
             HIPCHECK(hipEventRecord(ev_comm_done, comm_stream));
             HIPCHECK(hipStreamWaitEvent(c.s, ev_comm_done, 0));
         }
     }
-    void reduce_range(int64_t lo, int64_t hi, hipStream_t s) {
-        HIPCHECK(hipEventRecord(ev_bucket, s));
+    void reduce_range(int64_t lo, int64_t hi, const Ctx& c) {
+        HIPCHECK(hipEventRecord(ev_bucket, c.s));
         HIPCHECK(hipStreamWaitEvent(comm_stream, ev_bucket, 0));
+        if (c.side) {       // the bucket's weight gradients were queued on the side stream
+            HIPCHECK(hipEventRecord(ev_side_bucket, c.side));
+            HIPCHECK(hipStreamWaitEvent(comm_stream, ev_side_bucket, 0));
+        }
         NCCLCHECK(ncclAllReduce(flat_g + lo, flat_g + lo, (size_t)(hi - lo), ncclFloat, ncclSum, comm, comm_stream));
     }
     void run_adam(const Ctx& c) {
@@ -996,6 +1032,10 @@ struct p3d_handle {
         if (comm) ncclCommDestroy(comm);
         if (ev_bucket) hipEventDestroy(ev_bucket);
         if (ev_comm_done) hipEventDestroy(ev_comm_done);
+        for (hipEvent_t e : fork_events) hipEventDestroy(e);
+        if (ev_side_done) hipEventDestroy(ev_side_done);
+        if (ev_side_bucket) hipEventDestroy(ev_side_bucket);
+        if (side_stream) hipStreamDestroy(side_stream);
         for (void* p : allocs) hipFree(p);
         if (comm_stream) hipStreamDestroy(comm_stream);
         if (stream) hipStreamDestroy(stream);
@@ -1038,6 +1078,9 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         ensure_zero_page();
         HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        HIPCHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&h->ev_side_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_comm_done, hipEventDisableTiming));
         if (cfg->structure != P3D_STRUCTURE_UNET) throw P3dError("unknown structure");
@@ -1227,6 +1270,7 @@ int p3d_synchronize(p3d_handle* h) {
     if (!h) throw P3dError("null handle");
     HIPCHECK(hipSetDevice(h->cfg.device));
     HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipStreamSynchronize(h->side_stream));
     HIPCHECK(hipStreamSynchronize(h->comm_stream));
     API_END
 }
