@@ -84,19 +84,12 @@ def main():
     ap.add_argument("--dump-launches", default=None, help="write every launch record of the profiled step to this CSV")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from sap3d_tensorflow_amd.dp import Plane
+    plane = Plane()
+    world, rank, local_rank = plane.world, plane.rank, plane.local_rank
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
                          (args.gpus, world, args.gpus))
-
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only
 
     from sap3d_tensorflow_amd import P3DSession
     from oracle import p3d as oracle          # synthetic-input law only (dataflow.py:204-208)
@@ -104,9 +97,7 @@ def main():
     B = args.batch
     sess = P3DSession("unet", batch=B, device=local_rank, world_size=world, rank=rank, seed=1)
     if world > 1:
-        ids = [P3DSession.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        sess.comm_init(ids[0])
+        sess.comm_init(plane.share_from_rank0(P3DSession.comm_unique_id))
     x = oracle.synthetic_clip(rank, (B, 16, 112, 112, 3))
     y = oracle.synthetic_target(3 + rank, (B, 16, 112, 112))
     sess.upload(x, y)
@@ -114,20 +105,13 @@ def main():
     for i in range(args.warmup):
         sess.train_step_device(0.5, seed=i)
     sess.synchronize()
-    if dist:
-        dist.barrier()
+    plane.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         sess.train_step_device(0.5, seed=1000 + i)
     sess.synchronize()
-    if dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+    plane.barrier()
+    dt = plane.max_over_ranks(time.perf_counter() - t0)
     loss = sess.last_loss()
 
     if rank == 0:
@@ -161,9 +145,7 @@ def main():
                       (r["kernel"], r["launches"], r["ms"], r["avg_us"], r["tflops"], r["gbs"]), file=sys.stderr)
         print(json.dumps(out), flush=True)
     sess.close()
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    plane.close()
 
 
 if __name__ == "__main__":

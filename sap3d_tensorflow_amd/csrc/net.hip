@@ -1350,11 +1350,15 @@ int p3d_comm_unique_id(void* id_out) {
 int p3d_comm_init(p3d_handle* h, const void* idbytes) {
     API_BEGIN
     if (!h || !idbytes) throw P3dError("null argument");
-    if (h->cfg.world_size <= 1) throw P3dError("world_size is 1: no communicator needed");
+    if (h->cfg.world_size < 1) throw P3dError("bad world_size");      // world_size 1 is allowed (single-rank communicator, for tests)
     HIPCHECK(hipSetDevice(h->cfg.device));
     ncclUniqueId id;
     memcpy(&id, idbytes, sizeof(id));
     NCCLCHECK(ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
+    if (const char* e = getenv("P3D_BUCKET_MB")) {
+        const long mb = atol(e);
+        if (mb >= 1) h->bucket_floats = (int64_t)mb * (1 << 18);
+    }
     API_END
 }
 

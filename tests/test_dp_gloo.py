@@ -1,0 +1,74 @@
+"""Data-parallel path on CPU with world_size 2 (gloo): the control plane bench.py / the drivers use, and the
+arithmetic contract of the in-library all-reduce (SUM of per-shard gradients, because the reference loss is a
+batch SUM, utils/network.py:60) checked with the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oracle import p3d
+    from sap3d_tensorflow_amd.dp import Plane
+    plane = Plane()
+    ident = plane.share_from_rank0(lambda: b"id-from-rank0" + bytes(115))
+    lo, hi = plane.shard(4)
+    # per-shard oracle gradients, summed over ranks == what every replica holds after the all-reduce
+    cfg = p3d.NetConfig(base=8, blocks=(1, 1, 1))
+    params = p3d.init_params(1, 'unet', cfg, dtype=np.float64)
+    x = p3d.synthetic_clip(0, (4, 16, 32, 32, 3)).astype(np.float64)
+    y = p3d.synthetic_target(3, (4, 16, 32, 32)).astype(np.float64)
+    loss, _, grads, _ = p3d.loss_and_grads(params, x[lo:hi], y[lo:hi], 0.0, True, 'unet', cfg, np.float64)
+    names = sorted(grads)
+    arrs = [np.ascontiguousarray(grads[n]) for n in names]
+    plane.sum_arrays(arrs)
+    tmax = plane.max_over_ranks(1.0 + rank)
+    plane.barrier()
+    q.put((rank, ident[:13], (lo, hi), float(loss), {n: a for n, a in zip(names, arrs)}, tmax))
+    plane.close()
+
+
+def test_two_rank_control_plane_and_gradient_sum():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, id0, sh0, l0, g0, t0), (r1, id1, sh1, l1, g1, t1) = out
+    assert id0 == id1 == b"id-from-rank0"
+    assert sh0 == (0, 2) and sh1 == (2, 4)
+    assert t0 == t1 == 2.0                      # MAX over ranks
+    # both ranks hold the same summed gradients, equal to the sum of the two per-shard oracle gradients
+    sys.path.insert(0, ROOT)
+    from oracle import p3d
+    cfg = p3d.NetConfig(base=8, blocks=(1, 1, 1))
+    params = p3d.init_params(1, 'unet', cfg, dtype=np.float64)
+    x = p3d.synthetic_clip(0, (4, 16, 32, 32, 3)).astype(np.float64)
+    y = p3d.synthetic_target(3, (4, 16, 32, 32)).astype(np.float64)
+    want = None
+    for lo, hi in ((0, 2), (2, 4)):
+        _, _, g, _ = p3d.loss_and_grads(params, x[lo:hi], y[lo:hi], 0.0, True, 'unet', cfg, np.float64)
+        want = g if want is None else {n: want[n] + g[n] for n in g}
+    for n in want:
+        assert np.allclose(g0[n], want[n], rtol=1e-12, atol=1e-12), n
+        assert np.array_equal(g0[n], g1[n]), n
