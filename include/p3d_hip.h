@@ -22,7 +22,10 @@ extern "C" {
 
 typedef struct p3d_handle p3d_handle;
 
-enum { P3D_STRUCTURE_UNET = 0 };      /* train.py:149-150  --structure unet -> p3d.p3d_unet */
+enum {
+    P3D_STRUCTURE_UNET = 0,      /* train.py:149-150  --structure unet   -> p3d.p3d_unet   (p3d.py:169) */
+    P3D_STRUCTURE_CONCAT = 1     /* train.py:151-152  --structure concat -> p3d.p3d_concat (p3d.py:224), no sigmoid */
+};
 
 typedef struct p3d_config {
     int structure;        /* P3D_STRUCTURE_*                                                    */

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
                 const long long o = (((long long)n * Do + 2 * d + pd) * Ho + 2 * h + ph) * Wo + 2 * w;
                 const float v0 = out[(pd * 2 + ph) * 2], v1 = out[(pd * 2 + ph) * 2 + 1];
                 *reinterpret_cast<float2*>(a.logits + o) = make_float2(v0, v1);
-                *reinterpret_cast<float2*>(a.pred + o) = make_float2(1.f / (1.f + __expf(-v0)), 1.f / (1.f + __expf(-v1)));
+                *reinterpret_cast<float2*>(a.pred + o) =
+                    a.sigmoid ? make_float2(1.f / (1.f + __expf(-v0)), 1.f / (1.f + __expf(-v1))) : make_float2(v0, v1);
             }
     }
 }

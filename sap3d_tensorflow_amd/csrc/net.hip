@@ -787,7 +787,9 @@ struct p3d_handle {
         return bn_apply(B + "bn3", 1, y3, bn3, x, nullptr, nullptr, B + "out");
     }
 
-    void build_unet() {
+    // p3d.py:170-195: stem + three stages + temporal pools, shared verbatim by every head.  skip[0..1] are
+    // where pool2 / pool3 land (channel slices of decoder concat buffers for the unet head, or null).
+    void build_encoder(Act* skip2, Act* skip3, Act*& pool2, Act*& pool3, Act*& pool4) {
         const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
         if (T % 16 || H % 16 || W % 16) throw P3dError("frames/height/width must be multiples of 16");
         if (b % 8) throw P3dError("base must be a multiple of 8");
@@ -800,14 +802,10 @@ struct p3d_handle {
         Act* a1 = bn_apply("stem/bn", 0, c1, bn0, nullptr, nullptr, nullptr, "conv1_custom_bn_relu");
         const int k233[3] = {2, 3, 3}, s222[3] = {2, 2, 2}, k211[3] = {2, 1, 1}, s211[3] = {2, 1, 1};
         Act* cur = maxpool("pool1", a1, k233, s222, nullptr, "pool1");
-        // concat buffers of the decoder (p3d.py:203,208): [deconvN_re | poolM]
-        Act* cat1 = new_act("deconv1_concat", B, T / 8, H / 8, W / 8, 16 * b);
-        Act* cat2 = new_act("deconv2_concat", B, T / 4, H / 4, W / 4, 8 * b);
-        Act* pool2 = new_view(cat2, 4 * b, 4 * b, "pool2");
-        Act* pool3 = new_view(cat1, 8 * b, 8 * b, "pool3");
         int id = 0, inpl = b;
         const int planes[3] = {b, 2 * b, 4 * b};
-        Act* skips[3] = {pool2, pool3, nullptr};
+        Act* skips[3] = {skip2, skip3, nullptr};
+        Act* outs[3] = {nullptr, nullptr, nullptr};
         const char* pool_names[3] = {"pool2", "pool3", "pool4"};
         for (int stage = 0; stage < 3; ++stage) {
             for (int j = 0; j < cfg.blocks[stage]; ++j) {
@@ -816,8 +814,19 @@ struct p3d_handle {
                 ++id;
             }
             cur = maxpool(pool_names[stage], cur, k211, s211, skips[stage], pool_names[stage]);
+            outs[stage] = cur;
         }
-        Act* pool4 = cur;
+        pool2 = outs[0]; pool3 = outs[1]; pool4 = outs[2];
+    }
+
+    void build_unet() {
+        const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
+        const int k233[3] = {2, 3, 3}, s222[3] = {2, 2, 2};
+        // concat buffers of the decoder (p3d.py:203,208): [deconvN_re | poolM]
+        Act* cat1 = new_act("deconv1_concat", B, T / 8, H / 8, W / 8, 16 * b);
+        Act* cat2 = new_act("deconv2_concat", B, T / 4, H / 4, W / 4, 8 * b);
+        Act *pool2, *pool3, *pool4;
+        build_encoder(new_view(cat2, 4 * b, 4 * b, "pool2"), new_view(cat1, 8 * b, 8 * b, "pool3"), pool2, pool3, pool4);
         // decoder p3d.py:200-219
         const int k133[3] = {1, 3, 3}, k333[3] = {3, 3, 3}, k111[3] = {1, 1, 1}, s111[3] = {1, 1, 1};
         {
@@ -850,8 +859,43 @@ struct p3d_handle {
         head(c4, k5, b5);
     }
 
+    // p3d_concat (p3d.py:224-276, --structure concat): three skip deconvs to 4x28x28, channel concat, one dense
+    // 3x3x3 conv, one deconv, and a 1-channel deconv WITHOUT sigmoid.
+    void build_concat() {
+        const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
+        const int k333[3] = {3, 3, 3}, s111[3] = {1, 1, 1}, s222[3] = {2, 2, 2}, s444[3] = {4, 4, 4};
+        Act *pool2, *pool3, *pool4;
+        build_encoder(nullptr, nullptr, pool2, pool3, pool4);
+        Act* cat = new_act("concatenator", B, T / 4, H / 4, W / 4, 14 * b);
+        auto up = [&](const char* name, const char* bn_name, Act* x, int filters, const int* s, int coff) {
+            Param* k = conv_weight(std::string(name) + "/kernel", {3, 3, 3, filters, x->C});
+            Param* bi = add_param(std::string(name) + "/bias", {filters}, true, INIT_ZEROS);
+            BN* bn = add_bn(bn_name, filters, true);
+            Act* y = deconv(name, x, k, bi, k333, s, filters, bn, "");
+            bn_apply(bn_name, 0, y, bn, nullptr, nullptr, new_view(cat, coff, filters, ""), "");
+        };
+        up("deconv_pool2", "deconv_pool2_bn", pool2, 2 * b, s111, 0);
+        up("deconv_pool3", "deconv_pool3_bn", pool3, 4 * b, s222, 2 * b);
+        up("deconv_pool4", "deconv_pool4_bn", pool4, 8 * b, s444, 6 * b);
+        Param* kc = conv_weight("conv_concat/kernel", {3, 3, 3, 14 * b, 8 * b});
+        Param* bc = add_param("conv_concat/bias", {8 * b}, true, INIT_ZEROS);
+        BN* bnc = add_bn("conv_concat_bn", 8 * b, true);
+        Act* yc = conv("conv_concat", cat, kc, bc, k333, s111, 8 * b, bnc, "");
+        Act* zc = bn_apply("conv_concat_bn", 0, yc, bnc, nullptr, nullptr, nullptr, "conv_concat");
+        Param* kr = conv_weight("deconv_revise/kernel", {3, 3, 3, 2 * b, 8 * b});
+        Param* br = add_param("deconv_revise/bias", {2 * b}, true, INIT_ZEROS);
+        BN* bnr = add_bn("deconv1_revise_bn", 2 * b, true);
+        Act* yr = deconv("deconv_revise", zc, kr, br, k333, s222, 2 * b, bnr, "", /*bn_has_dropout=*/true);
+        Act* zr = bn_apply("deconv1_revise_bn", 0, yr, bnr, nullptr, nullptr, nullptr, "deconv1_revise", /*dropout=*/true);
+        Param* kp = conv_weight("predict_revise/kernel", {3, 3, 3, 1, 2 * b});
+        Param* bp = add_param("predict_revise/bias", {1}, true, INIT_ZEROS);
+        head(zr, kp, bp, /*with_sigmoid=*/false);
+    }
+
     // results = sigmoid(conv3d_transpose(x, 1, 3, 2)) (p3d.py:217-219) + Smooth-L1 (train.py:156-159)
-    void head(Act* x, Param* k, Param* bias) {
+    bool head_sigmoid = true;
+    void head(Act* x, Param* k, Param* bias, bool with_sigmoid = true) {
+        head_sigmoid = with_sigmoid;
         logits = new_act("logits", x->N, 2 * x->D, 2 * x->H, 2 * x->W, 1, false);
         pred = new_act("pred", x->N, 2 * x->D, 2 * x->H, 2 * x->W, 1, false);
         d_dlogits = dalloc<float>(pred->rows());
@@ -868,7 +912,7 @@ struct p3d_handle {
             HeadArgs a;
             memset(&a, 0, sizeof(a));
             a.x = x->p; a.N = x->N; a.D = x->D; a.H = x->H; a.W = x->W; a.C = x->C;
-            a.k = k->p; a.bias = bias->p; a.logits = logits->p; a.pred = pred->p;
+            a.k = k->p; a.bias = bias->p; a.logits = logits->p; a.pred = pred->p; a.sigmoid = with_sigmoid;
             a.dlogits = d_dlogits; a.dx = x->g; a.dk = k->g; a.dbias = bias->g;
             return a;
         };
@@ -959,7 +1003,7 @@ struct p3d_handle {
     }
     void run_loss(const Ctx& c) {
         HIPCHECK(hipMemsetAsync(d_loss, 0, sizeof(double), c.s));
-        launch(c, "smooth_l1_kernel", 0, 12.0 * pred->rows(), [&]() { return p3d_smooth_l1(pred->p, d_y, pred->rows(), d_loss, d_dlogits, 1, c.s); });
+        launch(c, "smooth_l1_kernel", 0, 12.0 * pred->rows(), [&]() { return p3d_smooth_l1(pred->p, d_y, pred->rows(), d_loss, d_dlogits, head_sigmoid ? 1 : 0, c.s); });
     }
     void run_backward(const Ctx& c0, bool allreduce) {
         Ctx c = c0; c.z0 = zb; c.z1 = zb + zb_bytes;
@@ -1083,11 +1127,12 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         HIPCHECK(hipEventCreateWithFlags(&h->ev_side_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_comm_done, hipEventDisableTiming));
-        if (cfg->structure != P3D_STRUCTURE_UNET) throw P3dError("unknown structure");
+        if (cfg->structure != P3D_STRUCTURE_UNET && cfg->structure != P3D_STRUCTURE_CONCAT) throw P3dError("unknown structure");
         if (cfg->batch < 1) throw P3dError("batch must be >= 1");
         for (int i = 0; i < 3; ++i)
             if (cfg->blocks[i] < 1) throw P3dError("blocks must be >= 1");
-        h->build_unet();
+        if (cfg->structure == P3D_STRUCTURE_CONCAT) h->build_concat();
+        else h->build_unet();
         h->finalize_build();
         HIPCHECK(hipStreamSynchronize(h->stream));
         *out = h;

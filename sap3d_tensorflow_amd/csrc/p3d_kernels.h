@@ -177,6 +177,7 @@ struct HeadArgs {
     const float* k;                        // kernel [3,3,3,1,C]
     const float* bias;                     // [1]
     float* logits; float* pred;            // pre- and post-sigmoid
+    int sigmoid;                           // 0: pred = logits (p3d_concat head, p3d.py:275)
     const float* dlogits; float* dx; float* dk; float* dbias;
 };
 hipError_t p3d_head_fwd(const HeadArgs& a, hipStream_t s);

@@ -33,10 +33,10 @@ def rel_l2(a, b, floor):
     return np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), floor)
 
 
-def make_session(cfg, shape, params):
+def make_session(cfg, shape, params, structure='unet'):
     from sap3d_tensorflow_amd import P3DSession
     B, T, H, W = shape
-    s = P3DSession('unet', batch=B, frames=T, height=H, width=W, base=cfg.base, blocks=cfg.blocks)
+    s = P3DSession(structure, batch=B, frames=T, height=H, width=W, base=cfg.base, blocks=cfg.blocks)
     s.load(params)
     return s
 
@@ -142,4 +142,28 @@ def test_dropout_statistics():
     kept = d[nz] != 0
     assert abs(kept.mean() - 0.5) < 0.02
     assert np.abs(d[nz][kept] - 2 * base[nz][kept]).max() < 2e-4
+    s.close()
+
+
+# ---- the concat head (train.py:151-152 --structure concat, p3d.py:224-276) ---------------------------------
+@pytest.mark.parametrize("cfg,shape", SMALL)
+def test_concat_head_forward_backward(cfg, shape):
+    p64 = randomise_norm_params(p3d.init_params(1, 'concat', cfg, dtype=np.float64))
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    x = p3d.synthetic_clip(0, shape + (3,))
+    y = p3d.synthetic_target(3, shape)
+    s = make_session(cfg, shape, p32, 'concat')
+    assert [n for n, _, _ in s.variables()] == list(p64)
+    for training in (False, True):
+        want, _ = p3d.forward(p64, x.astype(np.float64), 0.0, training, 'concat', cfg, np.float64)
+        got = s.forward(x, 0.0, training)
+        assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)      # raw (no sigmoid) outputs
+    l64, pr64, g64, _ = p3d.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True, 'concat', cfg, np.float64)
+    l32, _, g32, _ = p3d.loss_and_grads(dict(p32), x, y, 0.0, True, 'concat', cfg, np.float32)
+    loss, pred = s.backward(x, y, 0.0)
+    assert abs(loss - l64) < 1e-5 * abs(l64)
+    scale = np.median([np.linalg.norm(g) for g in g64.values()])
+    for n, want in g64.items():
+        floor = 1e-2 * scale
+        assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3, n
     s.close()
