@@ -129,3 +129,29 @@ def test_param_inventory_reference_arch():
     assert sum(1 for k in params if k.endswith('moving_mean')) == 195
     assert sum(1 for k, v in train.items() if v.ndim == 5) == 197
     assert params['batch_normalization_191/gamma'].shape == (1024,)
+
+
+def test_gn_cbam_net_fp64():
+    """gn/p3d_gn.py inference_p3d (GroupNorm, CBAM on every residual, concat head) vs torch autograd."""
+    from oracle import p3d_gn
+    cfg = p3d.NetConfig(base=8, blocks=(2, 2, 2))
+    params = p3d_gn.init_params(1, cfg, dtype=np.float64)
+    rng = np.random.default_rng(7)
+    for k, v in params.items():
+        if k.endswith('gamma'):
+            v[:] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith(('beta', '/bias')):
+            v[:] = rng.uniform(-0.3, 0.3, v.shape)
+    x = p3d.synthetic_clip(0, (2, 16, 32, 32, 3)).astype(np.float64)
+    y = p3d.synthetic_target(3, (2, 16, 32, 32)).astype(np.float64)
+    loss, pred, grads, g = p3d_gn.loss_and_grads(params, x, y, 0.0, True, cfg, np.float64)
+    m = torch_ref.TorchP3DGN(params, torch.float64, cfg.base, cfg.blocks)
+    tp = m.inference_p3d(torch.tensor(x))
+    tl = torch_ref.smooth_l1_sum(tp.reshape(y.shape), torch.tensor(y))
+    tl.backward()
+    assert abs(loss - tl.item()) <= 1e-10 * abs(tl.item())
+    assert np.abs(pred - tp.detach().numpy()).max() < 1e-10
+    scale = np.median([np.linalg.norm(gr) for gr in grads.values()])
+    assert len(grads) == len([k for k in m.p if m.p[k].requires_grad])
+    for n, gr in grads.items():
+        assert rel_l2(gr, m.p[n].grad.numpy(), 1e-4 * scale) < 1e-8, n

@@ -168,3 +168,70 @@ def smooth_l1_sum(pred, y):
     d = pred - y
     ad = d.abs()
     return torch.where(ad < 1, 0.5 * d * d, ad - 0.5).sum()
+
+
+class TorchP3DGN(TorchP3D):
+    """gn/p3d_gn.py inference_p3d (GroupNorm + CBAM on every residual) from a {tf_name: numpy} dict."""
+
+    def gn(self, x):
+        scope = self.uniq('group_norm')
+        C = x.shape[1]
+        return F.group_norm(x, min(32, C), self.p[scope + '/gamma'], self.p[scope + '/beta'], eps=1e-5)
+
+    def cbam(self, x, name):
+        p = self.p
+        k0, b0 = p[name + '/ch_at/mlp_0/kernel'], p[name + '/ch_at/mlp_0/bias']
+        k1, b1 = p[name + '/ch_at/mlp_1/kernel'], p[name + '/ch_at/mlp_1/bias']
+        mlp = lambda v: torch.relu(v @ k0 + b0) @ k1 + b1
+        avg = mlp(x.mean(dim=(2, 3, 4)))
+        mx = mlp(x.amax(dim=(2, 3, 4)))
+        x = x * torch.sigmoid(avg + mx)[:, :, None, None, None]
+        sp = torch.cat([x.mean(dim=1, keepdim=True), x.amax(dim=1, keepdim=True)], 1)
+        sp = conv3d_same(sp, p[name + '/sp_at/conv3d/kernel'], (1, 1, 1))
+        return x * torch.sigmoid(sp)
+
+    def block(self, x, i, inplanes, planes, first, stride2):
+        p = self.p
+        st = 'ABC'[i % 3]
+        s = (1, 2, 2) if (stride2 and first) else (1, 1, 1)
+        out = torch.relu(self.gn(conv3d_same(x, p['conv3_%d_1' % i], s)))
+        nm = 'ST%s_%d_2' % (st, i)
+        S = lambda t: conv3d_same(t, p[nm + '_S'], (1, 1, 1), p[nm + '_S_bias'])
+        T = lambda t: conv3d_same(t, p[nm + '_T'], (1, 1, 1), p[nm + '_T_bias'])
+        if st == 'A':
+            out = torch.relu(self.gn(T(torch.relu(self.gn(S(out))))))
+        elif st == 'B':
+            a = torch.relu(self.gn(S(out)))
+            out = torch.relu(self.gn(T(out))) + a
+        else:
+            a = torch.relu(self.gn(S(out)))
+            out = a + torch.relu(self.gn(T(a)))
+        out = self.gn(conv3d_same(out, p['conv3_%d_3' % i], (1, 1, 1)))
+        res = x
+        if first:
+            res = self.gn(conv3d_same(x, p['dw3d_%d' % i], s))
+        res = self.cbam(res, 'cbam_%d' % i)
+        return torch.relu(out + res)
+
+    def inference_p3d(self, x_ndhwc):
+        p, b = self.p, self.base
+        x = x_ndhwc.permute(0, 4, 1, 2, 3)
+        x = torch.relu(self.gn(conv3d_same(x, p['firstconv1'], (1, 2, 2))))
+        x = max_pool_same(x, (2, 3, 3), (2, 2, 2))
+        i, inpl = 0, b
+        pools = []
+        for stage, (n, planes) in enumerate(zip(self.blocks, (b, 2 * b, 4 * b))):
+            if stage == 2:      # deconv_pool3 and its GN are created before stage 3
+                d3 = torch.relu(self.gn(conv3d_transpose_same(pools[1], p['deconv_pool3/kernel'], (2, 2, 2), p['deconv_pool3/bias'])))
+            for j in range(n):
+                x = self.block(x, i, inpl, planes, j == 0, stage > 0)
+                inpl = planes * 4
+                i += 1
+            x = max_pool_same(x, (2, 1, 1), (2, 1, 1))
+            pools.append(x)
+        d4 = torch.relu(self.gn(conv3d_transpose_same(pools[2], p['deconv_pool4/kernel'], (4, 4, 4), p['deconv_pool4/bias'])))
+        c = torch.cat([d3, d4, pools[0]], 1)
+        c = torch.relu(self.gn(conv3d_same(c, p['conv_concat/kernel'], (1, 1, 1), p['conv_concat/bias'])))
+        c = torch.relu(self.gn(conv3d_transpose_same(c, p['deconv_revise/kernel'], (2, 2, 2), p['deconv_revise/bias'])))
+        c = conv3d_transpose_same(c, p['predict_revise/kernel'], (2, 2, 2), p['predict_revise/bias'])
+        return c.permute(0, 2, 3, 4, 1)
