@@ -1,0 +1,334 @@
+// CBAM on the bottleneck residual (reference utils/network.py:198-274, called at gn/p3d_gn.py:175) for gfx950.
+//   channel attention : cs[n,c] = sigmoid(MLP(mean_{dhw} x) + MLP(max_{dhw} x)),  MLP = C -> C/8 (ReLU) -> C, shared
+//   spatial attention : f = x*cs;  ss[pos] = sigmoid(conv7x7x7([mean_c f, max_c f]))   (2 -> 1 channels, no bias)
+//   output            : f * ss   -- never materialised: the block-end pass (gn_apply mode 6) multiplies in place.
+// The reference does ~3 extra full passes over the widest tensor of every block; here the forward touches x twice
+// (pool, channel-pool of x*cs) and the backward three times.  Everything else lives on [N,C] or [positions]
+// vectors.  reduce_max gradients are split equally between tied maxima (TF's _MinOrMaxGrad), which matters here
+// because x is post-ReLU and whole channels / positions can be zero.
+#include "p3d_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// (sum, max, ties) merge
+__device__ __forceinline__ void merge(float& s, float& m, float& t, float s2, float m2, float t2) {
+    s += s2;
+    if (m2 > m) { m = m2; t = t2; } else if (m2 == m) t += t2;
+}
+
+// grid (chunks, N); thread = channel (strided if C > 256); rows of the chunk are walked serially (coalesced over c)
+__global__ __launch_bounds__(256) void chan_pool_kernel(CbamArgs a) {
+    const int R = a.D * a.H * a.W;
+    const int n = blockIdx.y, ch = blockIdx.x;
+    const int per = (R + a.chunks - 1) / a.chunks;
+    const int r0 = ch * per, r1 = min(R, r0 + per);
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        float s = 0.f, m = -INFINITY, t = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const float v = a.x[((long long)n * R + r) * a.ld + c];
+            s += v;
+            if (v > m) { m = v; t = 1.f; } else if (v == m) t += 1.f;
+        }
+        float* o = a.part + (((long long)n * a.chunks + ch) * a.C + c) * 3;
+        o[0] = s; o[1] = m; o[2] = t;
+    }
+}
+
+// block per sample: fold the chunk partials, run the shared MLP on avg and max, cs = sigmoid(sum)
+__global__ __launch_bounds__(256) void chan_mlp_kernel(CbamArgs a) {
+    extern __shared__ float sm[];                  // avg[C] max[C] havg[Ch] hmax[Ch]
+    float* avg = sm; float* mx = sm + a.C; float* ha = mx + a.C; float* hm = ha + a.Ch;
+    const int R = a.D * a.H * a.W, n = blockIdx.x;
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        float s = 0.f, m = -INFINITY, t = 0.f;
+        for (int ch = 0; ch < a.chunks; ++ch) {
+            const float* o = a.part + (((long long)n * a.chunks + ch) * a.C + c) * 3;
+            merge(s, m, t, o[0], o[1], o[2]);
+        }
+        avg[c] = s / (float)R; mx[c] = m;
+        a.avg[(long long)n * a.C + c] = avg[c]; a.mx[(long long)n * a.C + c] = m; a.ties[(long long)n * a.C + c] = t;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < a.Ch; j += blockDim.x) {
+        float sa = a.b0[j], sb = a.b0[j];
+        for (int c = 0; c < a.C; ++c) { const float w = a.k0[c * a.Ch + j]; sa += avg[c] * w; sb += mx[c] * w; }
+        ha[j] = fmaxf(sa, 0.f); hm[j] = fmaxf(sb, 0.f);
+        a.havg[(long long)n * a.Ch + j] = ha[j]; a.hmx[(long long)n * a.Ch + j] = hm[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        float o = 2.f * a.b1[c];
+        for (int j = 0; j < a.Ch; ++j) o += (ha[j] + hm[j]) * a.k1[j * a.C + c];
+        a.cs[(long long)n * a.C + c] = sigm(o);
+    }
+}
+
+// wave per position: channel mean / max of f = x * cs
+__global__ __launch_bounds__(256) void spat_pool_kernel(CbamArgs a) {
+    const int R = a.D * a.H * a.W;
+    const long long M = (long long)a.N * R;
+    const int lane = threadIdx.x & 63;
+    for (long long pos = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pos < M; pos += (long long)gridDim.x * 4) {
+        const int n = (int)(pos / R);
+        float s = 0.f, m = -INFINITY;
+        for (int c = lane * 4; c < a.C; c += 256) {
+            const float4 v = ld4(a.x + pos * a.ld + c), k = ld4(a.cs + (long long)n * a.C + c);
+            const float f0 = v.x * k.x, f1 = v.y * k.y, f2 = v.z * k.z, f3 = v.w * k.w;
+            s += f0 + f1 + f2 + f3;
+            m = fmaxf(fmaxf(m, fmaxf(f0, f1)), fmaxf(f2, f3));
+        }
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); m = fmaxf(m, __shfl_xor(m, o)); }
+        if (lane == 0) { a.sp[pos * 2] = s / (float)a.C; a.sp[pos * 2 + 1] = m; }
+    }
+}
+
+// thread per position: 7x7x7 SAME conv over the 2-channel map, sigmoid
+__global__ __launch_bounds__(256) void spat_conv_kernel(CbamArgs a) {
+    __shared__ float kw[686];
+    for (int i = threadIdx.x; i < 686; i += blockDim.x) kw[i] = a.k7[i];
+    __syncthreads();
+    const int R = a.D * a.H * a.W;
+    const long long M = (long long)a.N * R;
+    for (long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += (long long)gridDim.x * blockDim.x) {
+        long long t = pos;
+        const int w = (int)(t % a.W); t /= a.W;
+        const int h = (int)(t % a.H); t /= a.H;
+        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+        float acc = 0.f;
+        for (int kd = 0; kd < 7; ++kd) {
+            const int id = d + kd - 3;
+            if ((unsigned)id >= (unsigned)a.D) continue;
+            for (int kh = 0; kh < 7; ++kh) {
+                const int ih = h + kh - 3;
+                if ((unsigned)ih >= (unsigned)a.H) continue;
+                for (int kk = 0; kk < 7; ++kk) {
+                    const int iw = w + kk - 3;
+                    if ((unsigned)iw >= (unsigned)a.W) continue;
+                    const float* sp = a.sp + ((((long long)n * a.D + id) * a.H + ih) * a.W + iw) * 2;
+                    const float* k = kw + ((kd * 7 + kh) * 7 + kk) * 2;
+                    acc += sp[0] * k[0] + sp[1] * k[1];
+                }
+            }
+        }
+        a.ss[pos] = sigm(acc);
+    }
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------
+// wave per position: dss = sum_c dout*f ; dpre = dss * ss * (1 - ss)
+__global__ __launch_bounds__(256) void bwd_dpre_kernel(CbamArgs a) {
+    const int R = a.D * a.H * a.W;
+    const long long M = (long long)a.N * R;
+    const int lane = threadIdx.x & 63;
+    for (long long pos = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pos < M; pos += (long long)gridDim.x * 4) {
+        const int n = (int)(pos / R);
+        float s = 0.f;
+        for (int c = lane * 4; c < a.C; c += 256) {
+            const float4 v = ld4(a.x + pos * a.ld + c), k = ld4(a.cs + (long long)n * a.C + c), g = ld4(a.dout + pos * a.C + c);
+            s += g.x * v.x * k.x + g.y * v.y * k.y + g.z * v.z * k.z + g.w * v.w * k.w;
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) { const float ss = a.ss[pos]; a.dpre[pos] = s * ss * (1.f - ss); }
+    }
+}
+
+// thread per position: dsp[pos][ch] = sum_taps dpre[pos - tap + 3] * K[tap][ch]   (transpose of the SAME conv)
+__global__ __launch_bounds__(256) void bwd_spat_conv_kernel(CbamArgs a) {
+    __shared__ float kw[686];
+    for (int i = threadIdx.x; i < 686; i += blockDim.x) kw[i] = a.k7[i];
+    __syncthreads();
+    const int R = a.D * a.H * a.W;
+    const long long M = (long long)a.N * R;
+    for (long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += (long long)gridDim.x * blockDim.x) {
+        long long t = pos;
+        const int w = (int)(t % a.W); t /= a.W;
+        const int h = (int)(t % a.H); t /= a.H;
+        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+        float a0 = 0.f, a1 = 0.f;
+        for (int kd = 0; kd < 7; ++kd) {
+            const int od = d - kd + 3;
+            if ((unsigned)od >= (unsigned)a.D) continue;
+            for (int kh = 0; kh < 7; ++kh) {
+                const int oh = h - kh + 3;
+                if ((unsigned)oh >= (unsigned)a.H) continue;
+                for (int kk = 0; kk < 7; ++kk) {
+                    const int ow = w - kk + 3;
+                    if ((unsigned)ow >= (unsigned)a.W) continue;
+                    const float g = a.dpre[(((long long)n * a.D + od) * a.H + oh) * a.W + ow];
+                    const float* k = kw + ((kd * 7 + kh) * 7 + kk) * 2;
+                    a0 += g * k[0]; a1 += g * k[1];
+                }
+            }
+        }
+        a.dsp[pos * 2] = a0; a.dsp[pos * 2 + 1] = a1;
+    }
+}
+
+// dK7[tap][ch] = sum_pos sp[pos + tap - 3][ch] * dpre[pos].  block per tap; threads stride over positions.
+__global__ __launch_bounds__(256) void bwd_k7_kernel(CbamArgs a) {
+    __shared__ float r0[256], r1[256];
+    const int tap = blockIdx.x;
+    const int kd = tap / 49, kh = (tap / 7) % 7, kk = tap % 7;
+    const int R = a.D * a.H * a.W;
+    const long long M = (long long)a.N * R;
+    float a0 = 0.f, a1 = 0.f;
+    for (long long pos = threadIdx.x; pos < M; pos += blockDim.x) {
+        long long t = pos;
+        const int w = (int)(t % a.W); t /= a.W;
+        const int h = (int)(t % a.H); t /= a.H;
+        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+        const int id = d + kd - 3, ih = h + kh - 3, iw = w + kk - 3;
+        if ((unsigned)id >= (unsigned)a.D || (unsigned)ih >= (unsigned)a.H || (unsigned)iw >= (unsigned)a.W) continue;
+        const float g = a.dpre[pos];
+        const float* sp = a.sp + ((((long long)n * a.D + id) * a.H + ih) * a.W + iw) * 2;
+        a0 += g * sp[0]; a1 += g * sp[1];
+    }
+    r0[threadIdx.x] = a0; r1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { unsafeAtomicAdd(a.dk7 + tap * 2, r0[0]); unsafeAtomicAdd(a.dk7 + tap * 2 + 1, r1[0]); }
+}
+
+// grid (chunks, N), wave per position inside the chunk: df = dout*ss + dmean/C + dmax*[f == max]/ties;
+// dx (+)= df*cs ; per-(n,c) partial of dcs = sum_pos df*x kept in registers, folded through LDS.
+__global__ __launch_bounds__(256) void bwd_df_kernel(CbamArgs a) {
+    extern __shared__ float red[];                 // [4][C]
+    const int R = a.D * a.H * a.W;
+    const int n = blockIdx.y, ch = blockIdx.x;
+    const int per = (R + a.chunks - 1) / a.chunks;
+    const int r0 = ch * per, r1 = min(R, r0 + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 dcs[4];                                  // C <= 1024: up to 4 float4 per lane
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dcs[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const long long pos = (long long)n * R + r;
+        const float ss = a.ss[pos], dmean = a.dsp[pos * 2] / (float)a.C, dmax = a.dsp[pos * 2 + 1], fmx = a.sp[pos * 2 + 1];
+        // ties of the channel max at this position
+        float ties = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane * 4 + q * 256;
+            if (c < a.C) {
+                const float4 v = ld4(a.x + pos * a.ld + c), k = ld4(a.cs + (long long)n * a.C + c);
+                ties += (v.x * k.x == fmx) + (v.y * k.y == fmx) + (v.z * k.z == fmx) + (v.w * k.w == fmx);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) ties += __shfl_xor(ties, o);
+        const float dmx = dmax / ties;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane * 4 + q * 256;
+            if (c < a.C) {
+                const float4 v = ld4(a.x + pos * a.ld + c), k = ld4(a.cs + (long long)n * a.C + c), g = ld4(a.dout + pos * a.C + c);
+                float4 df;
+                df.x = g.x * ss + dmean + (v.x * k.x == fmx ? dmx : 0.f);
+                df.y = g.y * ss + dmean + (v.y * k.y == fmx ? dmx : 0.f);
+                df.z = g.z * ss + dmean + (v.z * k.z == fmx ? dmx : 0.f);
+                df.w = g.w * ss + dmean + (v.w * k.w == fmx ? dmx : 0.f);
+                dcs[q].x += df.x * v.x; dcs[q].y += df.y * v.y; dcs[q].z += df.z * v.z; dcs[q].w += df.w * v.w;
+                float4 d = make_float4(df.x * k.x, df.y * k.y, df.z * k.z, df.w * k.w);
+                float* dst = a.dx + pos * a.lddx + c;
+                if (a.accx) { const float4 o = ld4(dst); d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w; }
+                st4(dst, d);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane * 4 + q * 256;
+        if (c < a.C) st4(red + wave * a.C + c, dcs[q]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x)
+        a.dcs_part[((long long)n * a.chunks + ch) * a.C + c] = red[c] + red[a.C + c] + red[2 * a.C + c] + red[3 * a.C + c];
+}
+
+// ONE block: loops over samples so the parameter gradients need no atomics.
+__global__ __launch_bounds__(256) void bwd_mlp_kernel(CbamArgs a) {
+    extern __shared__ float sm[];                  // dO[C] dha[Ch] dhm[Ch]
+    float* dO = sm; float* dha = sm + a.C; float* dhm = dha + a.Ch;
+    for (int n = 0; n < a.N; ++n) {
+        for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+            float s = 0.f;
+            for (int ch = 0; ch < a.chunks; ++ch) s += a.dcs_part[((long long)n * a.chunks + ch) * a.C + c];
+            const float cs = a.cs[(long long)n * a.C + c];
+            dO[c] = s * cs * (1.f - cs);
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < a.Ch; j += blockDim.x) {
+            float s = 0.f;
+            for (int c = 0; c < a.C; ++c) s += a.k1[j * a.C + c] * dO[c];
+            const float ha = a.havg[(long long)n * a.Ch + j], hm = a.hmx[(long long)n * a.Ch + j];
+            dha[j] = ha > 0.f ? s : 0.f; dhm[j] = hm > 0.f ? s : 0.f;
+            a.db0[j] += dha[j] + dhm[j];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+            const float av = a.avg[(long long)n * a.C + c], mv = a.mx[(long long)n * a.C + c];
+            float da = 0.f, dm = 0.f;
+            for (int j = 0; j < a.Ch; ++j) {
+                const float w = a.k0[c * a.Ch + j];
+                da += w * dha[j]; dm += w * dhm[j];
+                a.dk0[c * a.Ch + j] += av * dha[j] + mv * dhm[j];
+                a.dk1[j * a.C + c] += (a.havg[(long long)n * a.Ch + j] + a.hmx[(long long)n * a.Ch + j]) * dO[c];
+            }
+            a.db1[c] += 2.f * dO[c];
+            a.davg[(long long)n * a.C + c] = da; a.dmx[(long long)n * a.C + c] = dm;
+        }
+        __syncthreads();
+    }
+}
+
+// dx += davg/R + dmax * [x == max over the sample's rows] / ties
+__global__ __launch_bounds__(256) void bwd_chan_kernel(CbamArgs a) {
+    const int R = a.D * a.H * a.W, c4n = a.C >> 2;
+    const long long total = (long long)a.N * R * c4n;
+    const float invR = 1.f / (float)R;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pos = i / c4n;
+        const int c = (int)(i - pos * c4n) << 2;
+        const long long t = (pos / R) * a.C + c;
+        const float4 v = ld4(a.x + pos * a.ld + c), m = ld4(a.mx + t), ti = ld4(a.ties + t), da = ld4(a.davg + t), dm = ld4(a.dmx + t);
+        float* dst = a.dx + pos * a.lddx + c;
+        float4 d = ld4(dst);
+        d.x += da.x * invR + (v.x == m.x ? dm.x / ti.x : 0.f);
+        d.y += da.y * invR + (v.y == m.y ? dm.y / ti.y : 0.f);
+        d.z += da.z * invR + (v.z == m.z ? dm.z / ti.z : 0.f);
+        d.w += da.w * invR + (v.w == m.w ? dm.w / ti.w : 0.f);
+        st4(dst, d);
+    }
+}
+
+inline unsigned capped(long long b, int cap) { return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b)); }
+
+}  // namespace
+
+hipError_t p3d_cbam_forward(const CbamArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 1024 || a.Ch < 1 || a.chunks < 1) return hipErrorInvalidValue;
+    const long long M = (long long)a.N * a.D * a.H * a.W;
+    hipLaunchKernelGGL(chan_pool_kernel, dim3(a.chunks, a.N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chan_mlp_kernel, dim3(a.N), dim3(256), (2 * a.C + 2 * a.Ch) * sizeof(float), s, a);
+    hipLaunchKernelGGL(spat_pool_kernel, dim3(capped((M + 3) / 4, 8192)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(spat_conv_kernel, dim3(capped((M + 255) / 256, 4096)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t p3d_cbam_backward(const CbamArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
+    const long long M = (long long)a.N * a.D * a.H * a.W;
+    hipLaunchKernelGGL(bwd_dpre_kernel, dim3(capped((M + 3) / 4, 8192)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bwd_spat_conv_kernel, dim3(capped((M + 255) / 256, 4096)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bwd_k7_kernel, dim3(343), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bwd_df_kernel, dim3(a.chunks, a.N), dim3(256), 4 * a.C * sizeof(float), s, a);
+    hipLaunchKernelGGL(bwd_mlp_kernel, dim3(1), dim3(256), (a.C + 2 * a.Ch) * sizeof(float), s, a);
+    hipLaunchKernelGGL(bwd_chan_kernel, dim3(capped((M * (a.C >> 2) + 255) / 256, 4096)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

@@ -1,0 +1,314 @@
+// GroupNorm (reference gn/p3d_gn.py:24-46 == utils/network.py:65-87; eps 1e-5, G = min(32, C), statistics per
+// sample and group over (C/G, D, H, W)) and the fused normalise / ReLU / add passes of the GN bottleneck
+// (gn/p3d_gn.py:100-179), forward and backward, for gfx950.  NDHWC: a sample is R = D*H*W consecutive rows.
+//
+// The reference transposes to NCDHW and back around every GroupNorm; here nothing moves: per-(sample,
+// channel) sums are reduced where the data lies, a finalize pass folds the C/G channels of a group and emits
+// per-(sample, channel) scale/shift tables, and the apply pass is the BatchNorm apply with a table row per
+// sample.  Modes: 0 relu(gn(y1)); 1 relu(gn(y1) + r); 3 relu(gn(y1)) + relu(gn(y2)) (ST_B);
+// 4 r + relu(gn(y1)) (ST_C); 5 gn(y1); 6 relu(gn(y1) + r * cs[n,c] * ss[pos]) (CBAM-scaled residual,
+// gn/p3d_gn.py:175-177 with utils/network.py:249,274 folded in).
+#include "p3d_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
+__device__ __forceinline__ float4 gate4(float4 g, float4 pre) {
+    return make_float4(pre.x > 0.f ? g.x : 0.f, pre.y > 0.f ? g.y : 0.f, pre.z > 0.f ? g.z : 0.f, pre.w > 0.f ? g.w : 0.f);
+}
+__device__ __forceinline__ float u01(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float4 dropmask4(unsigned long long seed, long long e0, float rate, float scale) {
+    return make_float4(u01(seed, e0) >= rate ? scale : 0.f, u01(seed, e0 + 1) >= rate ? scale : 0.f,
+                       u01(seed, e0 + 2) >= rate ? scale : 0.f, u01(seed, e0 + 3) >= rate ? scale : 0.f);
+}
+
+// ---- statistics: sums[n][c] += (sum, sumsq) over a slice of the sample's rows.  grid = (row slices, N).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* y, int ld, int R, int C, double* sums) {
+    __shared__ float red[256][8];
+    const int c4n = C >> 2, rpi = 256 / c4n;
+    const int tid = threadIdx.x, sub = tid / c4n, c = (tid - sub * c4n) << 2;
+    const int n = blockIdx.y;
+    float4 s1 = f4(0.f), s2 = f4(0.f);
+    if (sub < rpi)
+        for (int r = blockIdx.x * rpi + sub; r < R; r += gridDim.x * rpi) {
+            const float4 v = ld4(y + ((long long)n * R + r) * ld + c);
+            s1 = add4(s1, v);
+            s2 = fma4(v, v, s2);
+        }
+    float* q = red[tid];
+    q[0] = s1.x; q[1] = s1.y; q[2] = s1.z; q[3] = s1.w; q[4] = s2.x; q[5] = s2.y; q[6] = s2.z; q[7] = s2.w;
+    __syncthreads();
+    if (tid < c4n) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = 0.f;
+        for (int s = 0; s < rpi; ++s)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] += red[s * c4n + tid][k];
+        double* dst = sums + ((long long)n * C + c) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsafeAtomicAdd(dst + 2 * k, (double)t[k]);
+            unsafeAtomicAdd(dst + 2 * k + 1, (double)t[4 + k]);
+        }
+    }
+}
+
+// ---- finalize: thread per (n, group) -> per-(n,c) scale / shift / mean / invstd tables
+__global__ void gn_finalize_kernel(GnParams p, int N, int R, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int G = p.G, cg = p.C / G;
+    if (i >= N * G) return;
+    const int n = i / G, g = i - n * G;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < cg; ++k) {
+        s1 += p.sums[((long long)n * p.C + g * cg + k) * 2];
+        s2 += p.sums[((long long)n * p.C + g * cg + k) * 2 + 1];
+    }
+    const double cnt = (double)R * cg;
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    for (int k = 0; k < cg; ++k) {
+        const int c = g * cg + k;
+        const long long o = (long long)n * p.C + c;
+        const double sc = (double)p.gamma[c] * inv;
+        p.scale[o] = (float)sc;
+        p.shift[o] = (float)((double)p.beta[c] - mean * sc);
+        p.mean[o] = (float)mean;
+        p.invstd[o] = (float)inv;
+    }
+}
+
+// ---- apply
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
+    const int c4n = a.C >> 2;
+    const long long total = a.M * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / c4n;
+        const int c = (int)(i - row * c4n) << 2;
+        const long long t = (row / a.R) * a.C + c;          // table row of this sample
+        const float4 v = fma4(ld4(a.g1.scale + t), ld4(a.y1 + row * a.ld1 + c), ld4(a.g1.shift + t));
+        float4 z;
+        if (MODE == 0) z = relu4(v);
+        else if (MODE == 5) z = v;
+        else if (MODE == 1) z = relu4(add4(v, ld4(a.y2 + row * a.ld2 + c)));
+        else if (MODE == 3) z = add4(relu4(v), relu4(fma4(ld4(a.g2.scale + t), ld4(a.y2 + row * a.ld2 + c), ld4(a.g2.shift + t))));
+        else if (MODE == 4) z = add4(ld4(a.y2 + row * a.ld2 + c), relu4(v));
+        else z = relu4(add4(v, mul4(mul4(ld4(a.y2 + row * a.ld2 + c), ld4(a.cs + t)), f4(a.ss[row]))));
+        if (a.drop_scale > 0.f) z = mul4(z, dropmask4(a.seed, row * a.C + c, a.drop_rate, a.drop_scale));
+        st4(a.z + row * a.ldz + c, z);
+    }
+}
+
+// gradient entering GN1 / GN2 (after gates) for one float4
+template <int MODE>
+__device__ __forceinline__ void gn_gates(const GnApplyArgs& a, long long row, int c, long long t, float4& g1, float4& g2,
+                                         float4& y1, float4& y2) {
+    float4 dz = ld4(a.dz + row * a.ldz + c);
+    if (a.drop_scale > 0.f) dz = mul4(dz, dropmask4(a.seed, row * a.C + c, a.drop_rate, a.drop_scale));
+    y1 = ld4(a.y1 + row * a.ld1 + c);
+    const float4 v1 = fma4(ld4(a.g1.scale + t), y1, ld4(a.g1.shift + t));
+    y2 = f4(0.f); g2 = f4(0.f);
+    if (MODE == 0) g1 = gate4(dz, v1);
+    else if (MODE == 5) g1 = dz;
+    else if (MODE == 1) { y2 = ld4(a.y2 + row * a.ld2 + c); g1 = gate4(dz, add4(v1, y2)); g2 = g1; }
+    else if (MODE == 3) {
+        y2 = ld4(a.y2 + row * a.ld2 + c);
+        const float4 v2 = fma4(ld4(a.g2.scale + t), y2, ld4(a.g2.shift + t));
+        g1 = gate4(dz, v1); g2 = gate4(dz, v2);
+    } else if (MODE == 4) { g1 = gate4(dz, v1); g2 = dz; }
+    else {
+        y2 = ld4(a.y2 + row * a.ld2 + c);
+        const float4 res = mul4(mul4(y2, ld4(a.cs + t)), f4(a.ss[row]));
+        g1 = gate4(dz, add4(v1, res)); g2 = g1;            // g2 = gradient w.r.t. the CBAM output
+    }
+}
+
+// per-(n,c) sums of g and g*xhat over a slice of the sample's rows.  grid = (row slices, N)
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnApplyArgs a) {
+    constexpr bool TWO = (MODE == 3);
+    __shared__ float red[256][TWO ? 16 : 8];
+    const int c4n = a.C >> 2, rpi = 256 / c4n;
+    const int tid = threadIdx.x, sub = tid / c4n, c = (tid - sub * c4n) << 2;
+    const int n = blockIdx.y;
+    const long long t = (long long)n * a.C + c;
+    float4 s1 = f4(0.f), sx1 = f4(0.f), s2 = f4(0.f), sx2 = f4(0.f);
+    if (sub < rpi) {
+        const float4 m1 = ld4(a.g1.mean + t), i1 = ld4(a.g1.invstd + t);
+        float4 m2 = f4(0.f), i2 = f4(0.f);
+        if (TWO) { m2 = ld4(a.g2.mean + t); i2 = ld4(a.g2.invstd + t); }
+        for (int r = blockIdx.x * rpi + sub; r < a.R; r += gridDim.x * rpi) {
+            const long long row = (long long)n * a.R + r;
+            float4 g1, g2, y1, y2;
+            gn_gates<MODE>(a, row, c, t, g1, g2, y1, y2);
+            s1 = add4(s1, g1);
+            sx1 = fma4(g1, mul4(sub4(y1, m1), i1), sx1);
+            if (TWO) { s2 = add4(s2, g2); sx2 = fma4(g2, mul4(sub4(y2, m2), i2), sx2); }
+        }
+    }
+    float* q = red[tid];
+    q[0] = s1.x; q[1] = s1.y; q[2] = s1.z; q[3] = s1.w; q[4] = sx1.x; q[5] = sx1.y; q[6] = sx1.z; q[7] = sx1.w;
+    if (TWO) { q[8] = s2.x; q[9] = s2.y; q[10] = s2.z; q[11] = s2.w; q[12] = sx2.x; q[13] = sx2.y; q[14] = sx2.z; q[15] = sx2.w; }
+    __syncthreads();
+    if (tid < c4n) {
+        constexpr int NV = TWO ? 16 : 8;
+        float tt[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) tt[k] = 0.f;
+        for (int s = 0; s < rpi; ++s)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) tt[k] += red[s * c4n + tid][k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsafeAtomicAdd(a.g1.sums + (t + k) * 2, (double)tt[k]);
+            unsafeAtomicAdd(a.g1.sums + (t + k) * 2 + 1, (double)tt[4 + k]);
+            if (TWO) {
+                unsafeAtomicAdd(a.g2.sums + (t + k) * 2, (double)tt[8 + k]);
+                unsafeAtomicAdd(a.g2.sums + (t + k) * 2 + 1, (double)tt[12 + k]);
+            }
+        }
+    }
+}
+
+// thread per (n, group): fold channels -> per-(n,c) coefficients  dy = k*g - c1 - xhat*c2
+__global__ void gn_bwd_finalize_kernel(GnParams p, int N, int R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int G = p.G, cg = p.C / G;
+    if (i >= N * G) return;
+    const int n = i / G, g = i - n * G;
+    double A = 0.0, B = 0.0;
+    for (int k = 0; k < cg; ++k) {
+        const int c = g * cg + k;
+        A += (double)p.gamma[c] * p.sums[((long long)n * p.C + c) * 2];
+        B += (double)p.gamma[c] * p.sums[((long long)n * p.C + c) * 2 + 1];
+    }
+    const double cnt = (double)R * cg;
+    for (int k = 0; k < cg; ++k) {
+        const int c = g * cg + k;
+        const long long o = (long long)n * p.C + c;
+        const double inv = p.invstd[o];
+        p.coef[o * 3 + 0] = (float)((double)p.gamma[c] * inv);
+        p.coef[o * 3 + 1] = (float)(inv * A / cnt);
+        p.coef[o * 3 + 2] = (float)(inv * B / cnt);
+    }
+}
+// thread per channel: dgamma = sum_n sum(g*xhat), dbeta = sum_n sum(g)
+__global__ void gn_bwd_params_kernel(GnParams p, int N, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        s1 += p.sums[((long long)n * p.C + c) * 2];
+        s2 += p.sums[((long long)n * p.C + c) * 2 + 1];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+}
+
+__device__ __forceinline__ float4 gn_dx(const GnParams& g, long long t, float4 gr, float4 y) {
+    const float4 xh = mul4(sub4(y, ld4(g.mean + t)), ld4(g.invstd + t));
+    const float* cf = g.coef + t * 3;       // 4 channels x (k, c1, c2)
+    const float4 a = ld4(cf), b = ld4(cf + 4), c = ld4(cf + 8);
+    const float4 k = make_float4(a.x, a.w, b.z, c.y), c1 = make_float4(a.y, b.x, b.w, c.z), c2 = make_float4(a.z, b.y, c.x, c.w);
+    return sub4(sub4(mul4(k, gr), c1), mul4(xh, c2));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnApplyArgs a) {
+    const int c4n = a.C >> 2;
+    const long long total = a.M * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / c4n;
+        const int c = (int)(i - row * c4n) << 2;
+        const long long t = (row / a.R) * a.C + c;
+        float4 g1, g2, y1, y2;
+        gn_gates<MODE>(a, row, c, t, g1, g2, y1, y2);
+        st4(a.dy1 + row * a.lddy1 + c, gn_dx(a.g1, t, g1, y1));
+        if (MODE == 1 || MODE == 3 || MODE == 4 || MODE == 6) {
+            float4 d = (MODE == 3) ? gn_dx(a.g2, t, g2, y2) : g2;
+            float* dst = a.dy2 + row * a.lddy2 + c;
+            if (a.acc2) d = add4(d, ld4(dst));
+            st4(dst, d);
+        }
+    }
+}
+
+inline unsigned grid_for(long long total, int cap = 4096) {
+    long long b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+inline dim3 slice_grid(int R, int C, int N) {
+    const int rpi = 256 / (C >> 2);
+    long long bx = (R + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
+    if (bx < 1) bx = 1;
+    if (bx > 256) bx = 256;
+    return dim3((unsigned)bx, (unsigned)N);
+}
+
+}  // namespace
+
+hipError_t p3d_gn_stats(const float* y, int ld, int N, int R, int C, double* sums, hipStream_t s) {
+    if ((C & 3) || C > 1024 || (ld & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_stats_kernel, slice_grid(R, C, N), dim3(256), 0, s, y, ld, R, C, sums);
+    return hipGetLastError();
+}
+hipError_t p3d_gn_finalize(const GnParams& p, int N, int R, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * p.G + 255) / 256), dim3(256), 0, s, p, N, R, eps);
+    return hipGetLastError();
+}
+
+#define P3D_GN_SWITCH(KERNEL, GRID)                                                         \
+    switch (a.mode) {                                                                       \
+        case 0: hipLaunchKernelGGL(KERNEL<0>, GRID, dim3(256), 0, s, a); break;             \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), 0, s, a); break;             \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(256), 0, s, a); break;             \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), 0, s, a); break;             \
+        case 5: hipLaunchKernelGGL(KERNEL<5>, GRID, dim3(256), 0, s, a); break;             \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, GRID, dim3(256), 0, s, a); break;             \
+        default: return hipErrorInvalidValue;                                               \
+    }
+
+hipError_t p3d_gn_apply(const GnApplyArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
+    const dim3 g(grid_for(a.M * (a.C >> 2)));
+    P3D_GN_SWITCH(gn_apply_kernel, g)
+    return hipGetLastError();
+}
+hipError_t p3d_gn_bwd_reduce(const GnApplyArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
+    const dim3 g = slice_grid(a.R, a.C, (int)(a.M / a.R));
+    P3D_GN_SWITCH(gn_bwd_reduce_kernel, g)
+    return hipGetLastError();
+}
+hipError_t p3d_gn_bwd_finalize(const GnParams& p, int N, int R, float* dgamma, float* dbeta, hipStream_t s) {
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((N * p.G + 255) / 256), dim3(256), 0, s, p, N, R);
+    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((p.C + 255) / 256), dim3(256), 0, s, p, N, dgamma, dbeta);
+    return hipGetLastError();
+}
+hipError_t p3d_gn_bwd_apply(const GnApplyArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
+    const dim3 g(grid_for(a.M * (a.C >> 2)));
+    P3D_GN_SWITCH(gn_bwd_apply_kernel, g)
+    return hipGetLastError();
+}

@@ -45,7 +45,7 @@ struct P3dError : std::runtime_error {
         if (r_ != ncclSuccess) throw P3dError(std::string(#expr) + " failed: " + ncclGetErrorString(r_)); \
     } while (0)
 
-enum InitKind { INIT_XAVIER = 0, INIT_ZEROS = 1, INIT_ONES = 2 };
+enum InitKind { INIT_XAVIER = 0, INIT_ZEROS = 1, INIT_ONES = 2, INIT_VS = 3 };
 
 struct Param {
     std::string name;
@@ -89,6 +89,24 @@ struct Prof {
     std::vector<ProfRec> recs;
     int phase = 0;
     std::string cur_op;
+};
+
+struct GN {                            // one GroupNorm layer (gn/p3d_gn.py:24-46)
+    std::string name;
+    int C = 0, G = 0, N = 0;
+    Param *gamma = nullptr, *beta = nullptr;
+    int64_t sums_off = 0;              // forward (sum, sumsq) in the stats arena   [N][C][2] doubles
+    int64_t bsums_off = 0;             // backward sums in the reduction arena       [N][C][2] doubles
+    int64_t tab_off = 0;               // scale, shift, mean, invstd [N][C] each + coef [N][C][3], in bnbuf
+};
+
+struct CbamSite {                      // one cbam_block on a bottleneck residual (utils/network.py:198-274)
+    Param *k0 = nullptr, *b0 = nullptr, *k1 = nullptr, *b1 = nullptr, *k7 = nullptr;
+    Act* x = nullptr;
+    float* dout = nullptr;             // gradient of the CBAM output, written by the block-end pass
+    int chunks = 1;
+    int64_t buf_off = 0;               // float scratch in bnbuf
+    char* xflag = nullptr;
 };
 
 struct Ctx {
@@ -393,6 +411,8 @@ struct p3d_handle {
     std::deque<Act> acts;
     std::map<std::string, Act*> named;
     std::deque<BN> bns;
+    std::deque<GN> gns;
+    std::deque<CbamSite> cbams;
     std::deque<char> flags;
     std::map<std::string, int> uniq;
 
@@ -721,6 +741,244 @@ struct p3d_handle {
         };
         ops.push_back(op);
         return out;
+    }
+
+    // ---- GroupNorm / CBAM variant (gn/p3d_gn.py) ---------------------------------------------------
+    GN* add_gn(int C) {
+        gns.emplace_back();
+        GN* g = &gns.back();
+        g->name = unique("group_norm");
+        g->C = C; g->G = C < 32 ? C : 32; g->N = cfg.batch;
+        g->gamma = add_param(g->name + "/gamma", {C}, true, INIT_ONES);
+        g->beta = add_param(g->name + "/beta", {C}, true, INIT_ZEROS);
+        const int64_t nc = (int64_t)cfg.batch * C;
+        g->sums_off = stats_count; stats_count += 2 * nc;
+        g->bsums_off = red_count; red_count += 2 * nc;
+        g->tab_off = bnbuf_count; bnbuf_count += 7 * nc;
+        return g;
+    }
+    GnParams gn_params(GN* g, bool bwd) {
+        GnParams p;
+        const int64_t nc = (int64_t)g->N * g->C;
+        p.gamma = g->gamma->p; p.beta = g->beta->p;
+        p.sums = bwd ? red_arena + g->bsums_off : stats_arena + g->sums_off;
+        float* t = bnbuf + g->tab_off;
+        p.scale = t; p.shift = t + nc; p.mean = t + 2 * nc; p.invstd = t + 3 * nc; p.coef = t + 4 * nc;
+        p.C = g->C; p.G = g->G;
+        return p;
+    }
+
+    // GroupNorm + fused activation pass (modes in gn.hip).  cb != null: mode 6, y2 is the CBAM input.
+    Act* gn_apply(const std::string& opname, int mode, Act* y1, GN* g1, Act* y2, GN* g2, Act* out, const std::string& out_name,
+                  bool dropout = false, CbamSite* cb = nullptr) {
+        if (!out) out = new_act(out_name, y1->N, y1->D, y1->H, y1->W, y1->C);
+        else if (!out_name.empty()) named[out_name] = out;
+        consume(y1);
+        char* f2 = nullptr;
+        if (y2 && mode != 6) f2 = consume(y2);
+        const int64_t M = y1->rows();
+        const int R = y1->D * y1->H * y1->W, C = y1->C, N = y1->N;
+        const double tens = (double)M * C * 4.0;
+        const std::string ka = "gn_apply_kernel<" + std::to_string(mode) + ">";
+        const std::string kr = "gn_bwd_reduce_kernel<" + std::to_string(mode) + ">";
+        const std::string kb = "gn_bwd_apply_kernel<" + std::to_string(mode) + ">";
+        Op op;
+        op.name = opname; op.kind = "gn_apply" + std::to_string(mode);
+        op.bytes = tens * (y2 ? 4 : 3); op.bbytes = tens * (y2 ? 7 : 5);
+        op.first_param_off = g1->gamma->off;
+        if (g2 && g2->gamma->off < op.first_param_off) op.first_param_off = g2->gamma->off;
+        auto mk = [=](const Ctx& c, bool bwd) {
+            GnApplyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.mode = mode; a.M = M; a.R = R; a.C = C;
+            a.y1 = y1->p; a.ld1 = y1->ld; a.g1 = gn_params(g1, bwd);
+            if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; }
+            if (g2) a.g2 = gn_params(g2, bwd);
+            if (cb) { a.cs = bnbuf + cb->buf_off + cbam_cs_off(cb); a.ss = bnbuf + cb->buf_off + cbam_ss_off(cb); }
+            a.z = out->p; a.ldz = out->ld; a.dz = out->g;
+            a.dy1 = y1->g; a.lddy1 = y1->ld;
+            if (mode == 6) { a.dy2 = cb->dout; a.lddy2 = C; a.acc2 = 0; }
+            else if (y2) { a.dy2 = y2->g; a.lddy2 = y2->ld; a.acc2 = *f2; }
+            if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
+            return a;
+        };
+        op.fwd = [=](const Ctx& c) {
+            const GnApplyArgs a = mk(c, false);
+            launch(c, "gn_stats_kernel", 0, tens, [&]() { return p3d_gn_stats(y1->p, y1->ld, N, R, C, a.g1.sums, c.s); });
+            launch(c, "gn_finalize_kernel", 0, 32.0 * N * C, [&]() { return p3d_gn_finalize(a.g1, N, R, 1e-5f, c.s); });
+            if (mode == 3) {
+                launch(c, "gn_stats_kernel", 0, tens, [&]() { return p3d_gn_stats(y2->p, y2->ld, N, R, C, a.g2.sums, c.s); });
+                launch(c, "gn_finalize_kernel", 0, 32.0 * N * C, [&]() { return p3d_gn_finalize(a.g2, N, R, 1e-5f, c.s); });
+            }
+            launch(c, ka.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_gn_apply(a, c.s); });
+        };
+        op.bwd = [=](const Ctx& c) {
+            const GnApplyArgs a = mk(c, true);
+            launch(c, kr.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_gn_bwd_reduce(a, c.s); });
+            launch(c, "gn_bwd_finalize_kernel", 0, 64.0 * N * C, [&]() { return p3d_gn_bwd_finalize(a.g1, N, R, g1->gamma->g, g1->beta->g, c.s); });
+            if (mode == 3)
+                launch(c, "gn_bwd_finalize_kernel", 0, 64.0 * N * C, [&]() { return p3d_gn_bwd_finalize(a.g2, N, R, g2->gamma->g, g2->beta->g, c.s); });
+            launch(c, kb.c_str(), 0, tens * (y2 ? 5 : 3), [&]() { return p3d_gn_bwd_apply(a, c.s); });
+        };
+        ops.push_back(op);
+        return out;
+    }
+
+    // scratch layout of one CBAM site inside bnbuf (floats)
+    static int64_t cbam_part_off(CbamSite*) { return 0; }
+    int64_t cbam_vec_off(CbamSite* cb) { return (int64_t)cb->x->N * cb->chunks * cb->x->C * 3; }                // avg, mx, ties, cs, davg, dmx: [N][C] each
+    int64_t cbam_cs_off(CbamSite* cb) { return cbam_vec_off(cb) + 3 * (int64_t)cb->x->N * cb->x->C; }
+    int64_t cbam_h_off(CbamSite* cb) { return cbam_vec_off(cb) + 6 * (int64_t)cb->x->N * cb->x->C; }            // havg, hmx [N][C/8]
+    int64_t cbam_sp_off(CbamSite* cb) { return cbam_h_off(cb) + 2 * (int64_t)cb->x->N * (cb->x->C / 8) + 8; }   // sp [M][2]
+    int64_t cbam_ss_off(CbamSite* cb) { return cbam_sp_off(cb) + 2 * cb->x->rows(); }                          // ss [M]
+    int64_t cbam_dpre_off(CbamSite* cb) { return cbam_ss_off(cb) + cb->x->rows(); }                             // dpre [M]
+    int64_t cbam_dsp_off(CbamSite* cb) { return cbam_dpre_off(cb) + cb->x->rows(); }                            // dsp [M][2]
+    int64_t cbam_dcs_off(CbamSite* cb) { return cbam_dsp_off(cb) + 2 * cb->x->rows(); }                         // dcs_part [N][chunks][C]
+    int64_t cbam_total(CbamSite* cb) { return ((cbam_dcs_off(cb) + (int64_t)cb->x->N * cb->chunks * cb->x->C + 63) / 64) * 64; }
+
+    CbamArgs cbam_args(CbamSite* cb) {
+        CbamArgs a;
+        memset(&a, 0, sizeof(a));
+        Act* x = cb->x;
+        const int64_t nc = (int64_t)x->N * x->C;
+        float* b = bnbuf + cb->buf_off;
+        a.x = x->p; a.ld = x->ld; a.N = x->N; a.D = x->D; a.H = x->H; a.W = x->W; a.C = x->C; a.Ch = x->C / 8;
+        a.k0 = cb->k0->p; a.b0 = cb->b0->p; a.k1 = cb->k1->p; a.b1 = cb->b1->p; a.k7 = cb->k7->p;
+        a.chunks = cb->chunks;
+        a.part = b + cbam_part_off(cb);
+        float* v = b + cbam_vec_off(cb);
+        a.avg = v; a.mx = v + nc; a.ties = v + 2 * nc; a.cs = v + 3 * nc; a.davg = v + 4 * nc; a.dmx = v + 5 * nc;
+        a.havg = b + cbam_h_off(cb); a.hmx = a.havg + (int64_t)x->N * a.Ch;
+        a.sp = b + cbam_sp_off(cb); a.ss = b + cbam_ss_off(cb); a.dpre = b + cbam_dpre_off(cb); a.dsp = b + cbam_dsp_off(cb);
+        a.dcs_part = b + cbam_dcs_off(cb);
+        a.dout = cb->dout;
+        a.dx = x->g; a.lddx = x->ld; a.accx = cb->xflag ? *cb->xflag : 0;
+        a.dk0 = cb->k0->g; a.db0 = cb->b0->g; a.dk1 = cb->k1->g; a.db1 = cb->b1->g; a.dk7 = cb->k7->g;
+        return a;
+    }
+
+    // residual = cbam_block(residual, 'cbam_<id>')  (gn/p3d_gn.py:175)
+    CbamSite* cbam(Act* x, int id) {
+        cbams.emplace_back();
+        CbamSite* cb = &cbams.back();
+        const std::string nm = "cbam_" + std::to_string(id);
+        const int C = x->C, Ch = C / 8;
+        if (Ch < 1) throw P3dError("CBAM needs at least 8 channels");
+        cb->k0 = add_param(nm + "/ch_at/mlp_0/kernel", {C, Ch}, true, INIT_VS);
+        cb->b0 = add_param(nm + "/ch_at/mlp_0/bias", {Ch}, true, INIT_ZEROS);
+        cb->k1 = add_param(nm + "/ch_at/mlp_1/kernel", {Ch, C}, true, INIT_VS);
+        cb->b1 = add_param(nm + "/ch_at/mlp_1/bias", {C}, true, INIT_ZEROS);
+        cb->k7 = add_param(nm + "/sp_at/conv3d/kernel", {7, 7, 7, 2, 1}, true, INIT_VS);
+        cb->x = x;
+        const int R = x->D * x->H * x->W;
+        int chunks = R / 16;
+        if (chunks < 1) chunks = 1;
+        if (chunks > 64) chunks = 64;
+        cb->chunks = chunks;
+        cb->dout = dalloc<float>(x->rows() * C);
+        cb->buf_off = bnbuf_count; bnbuf_count += cbam_total(cb);
+        cb->xflag = consume(x);
+        Op op;
+        op.name = "block" + std::to_string(id) + "/cbam"; op.kind = "cbam";
+        op.bytes = 4.0 * 2 * x->rows() * C; op.bbytes = 4.0 * 7 * x->rows() * C;
+        op.first_param_off = cb->k0->off;
+        op.fwd = [=](const Ctx& c) { launch(c, "cbam_forward(4 kernels)", 0, 8.0 * x->rows() * C, [&]() { return p3d_cbam_forward(cbam_args(cb), c.s); }); };
+        op.bwd = [=](const Ctx& c) { launch(c, "cbam_backward(6 kernels)", 0, 28.0 * x->rows() * C, [&]() { return p3d_cbam_backward(cbam_args(cb), c.s); }); };
+        ops.push_back(op);
+        return cb;
+    }
+
+    // Bottleneck.infer of the GN file, gn/p3d_gn.py:127-179
+    Act* bottleneck_gn(Act* x, int id, int inplanes, int planes, bool first, bool stride2) {
+        const std::string sid = std::to_string(id);
+        const char st = "ABC"[id % 3];
+        const int one[3] = {1, 1, 1}, s2[3] = {1, 2, 2};
+        const int* s = (first && stride2) ? s2 : one;
+        const int kS[3] = {1, 3, 3}, kT[3] = {3, 1, 1};
+        const std::string B = "block" + sid + "/";
+        Param* w1 = conv_weight("conv3_" + sid + "_1", {1, 1, 1, inplanes, planes});
+        GN* g1 = add_gn(planes);
+        Act* y1 = conv(B + "conv1", x, w1, nullptr, one, s, planes, nullptr, "");
+        Act* z1 = gn_apply(B + "gn1", 0, y1, g1, nullptr, nullptr, nullptr, B + "conv1_bn_relu");
+        const std::string nm = std::string("ST") + st + "_" + sid + "_2";
+        Param* wS = conv_weight(nm + "_S", {1, 3, 3, planes, planes});
+        Param* bS = conv_weight(nm + "_S_bias", {planes});
+        GN* gS = add_gn(planes);
+        Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, nullptr, "");
+        Act* zS = (st == 'B') ? nullptr : gn_apply(B + "gnS", 0, yS, gS, nullptr, nullptr, nullptr, "");
+        Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
+        Param* bT = conv_weight(nm + "_T_bias", {planes});
+        GN* gT = add_gn(planes);
+        Act* yT = conv(B + "convT", st == 'B' ? z1 : zS, wT, bT, kT, one, planes, nullptr, "");
+        Act* stout;
+        if (st == 'A') stout = gn_apply(B + "gnT", 0, yT, gT, nullptr, nullptr, nullptr, B + "st");
+        else if (st == 'B') stout = gn_apply(B + "gnST", 3, yT, gT, yS, gS, nullptr, B + "st");      // relu(gn(T)) + relu(gn(S))
+        else stout = gn_apply(B + "gnT", 4, yT, gT, zS, nullptr, nullptr, B + "st");
+        Param* w3 = conv_weight("conv3_" + sid + "_3", {1, 1, 1, planes, planes * 4});
+        GN* g3 = add_gn(planes * 4);
+        Act* y3 = conv(B + "conv3", stout, w3, nullptr, one, one, planes * 4, nullptr, "");
+        Act* res = x;
+        if (first) {
+            Param* wp = conv_weight("dw3d_" + sid, {1, 1, 1, inplanes, planes * 4});
+            GN* gp = add_gn(planes * 4);
+            Act* yp = conv(B + "proj", x, wp, nullptr, one, s, planes * 4, nullptr, "");
+            res = gn_apply(B + "gnp", 5, yp, gp, nullptr, nullptr, nullptr, "");
+        }
+        CbamSite* cb = cbam(res, id);
+        return gn_apply(B + "gn3", 6, y3, g3, res, nullptr, nullptr, B + "out", false, cb);
+    }
+
+    // inference_p3d, gn/p3d_gn.py:214-258
+    void build_gn_p3d() {
+        const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
+        if (T % 16 || H % 16 || W % 16) throw P3dError("frames/height/width must be multiples of 16");
+        if (b % 8) throw P3dError("base must be a multiple of 8");
+        x_in = new_act("x", B, T, H, W, 3, false);
+        const int k177[3] = {1, 7, 7}, s122[3] = {1, 2, 2}, k233[3] = {2, 3, 3}, s222[3] = {2, 2, 2};
+        const int k211[3] = {2, 1, 1}, s211[3] = {2, 1, 1}, k333[3] = {3, 3, 3}, s111[3] = {1, 1, 1}, s444[3] = {4, 4, 4};
+        Param* w0 = conv_weight("firstconv1", {1, 7, 7, 3, b});
+        GN* g0 = add_gn(b);
+        Act* c1 = conv("stem/conv", x_in, w0, nullptr, k177, s122, b, nullptr, "conv1_custom", true);
+        Act* a1 = gn_apply("stem/gn", 0, c1, g0, nullptr, nullptr, nullptr, "conv1_custom_bn_relu");
+        Act* cur = maxpool("pool1", a1, k233, s222, nullptr, "pool1");
+        // concatenator = [deconv_pool3_gn (8b) | deconv_pool4_gn (16b) | pool2 (4b)]  (gn/p3d_gn.py:251)
+        Act* cat = new_act("concatenator", B, T / 4, H / 4, W / 4, 28 * b);
+        int id = 0, inpl = b;
+        const int planes[3] = {b, 2 * b, 4 * b};
+        Act* pools[3] = {nullptr, nullptr, nullptr};
+        Act* skips[3] = {new_view(cat, 24 * b, 4 * b, "pool2"), nullptr, nullptr};
+        const char* pool_names[3] = {"pool2", "pool3", "pool4"};
+        auto up = [&](const char* name, Act* x, int filters, const int* s, int coff) {
+            Param* k = conv_weight(std::string(name) + "/kernel", {3, 3, 3, filters, x->C});
+            Param* bi = add_param(std::string(name) + "/bias", {filters}, true, INIT_ZEROS);
+            GN* g = add_gn(filters);
+            Act* y = deconv(name, x, k, bi, k333, s, filters, nullptr, "");
+            gn_apply(std::string(name) + "_gn", 0, y, g, nullptr, nullptr, new_view(cat, coff, filters, ""), "");
+        };
+        for (int stage = 0; stage < 3; ++stage) {
+            if (stage == 2) up("deconv_pool3", pools[1], 8 * b, s222, 0);      // created before stage 3
+            for (int j = 0; j < cfg.blocks[stage]; ++j) {
+                cur = bottleneck_gn(cur, id, inpl, planes[stage], j == 0, stage > 0);
+                inpl = planes[stage] * 4;
+                ++id;
+            }
+            cur = maxpool(pool_names[stage], cur, k211, s211, skips[stage], pool_names[stage]);
+            pools[stage] = cur;
+        }
+        up("deconv_pool4", pools[2], 16 * b, s444, 8 * b);
+        Param* kc = conv_weight("conv_concat/kernel", {3, 3, 3, 28 * b, 16 * b});
+        Param* bc = add_param("conv_concat/bias", {16 * b}, true, INIT_ZEROS);
+        GN* gc = add_gn(16 * b);
+        Act* yc = conv("conv_concat", cat, kc, bc, k333, s111, 16 * b, nullptr, "");
+        Act* zc = gn_apply("conv_concat_gn", 0, yc, gc, nullptr, nullptr, nullptr, "conv_concat");
+        Param* kr = conv_weight("deconv_revise/kernel", {3, 3, 3, 4 * b, 16 * b});
+        Param* br = add_param("deconv_revise/bias", {4 * b}, true, INIT_ZEROS);
+        GN* gr = add_gn(4 * b);
+        Act* yr = deconv("deconv_revise", zc, kr, br, k333, s222, 4 * b, nullptr, "");
+        Act* zr = gn_apply("deconv_revise_gn", 0, yr, gr, nullptr, nullptr, nullptr, "deconv_revise", /*dropout=*/true);
+        Param* kp = conv_weight("predict_revise/kernel", {3, 3, 3, 1, 4 * b});
+        Param* bp = add_param("predict_revise/bias", {1}, true, INIT_ZEROS);
+        head(zr, kp, bp, /*with_sigmoid=*/false);
     }
 
     // ---- the reference graph -------------------------------------------------------------------
@@ -1127,11 +1385,12 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         HIPCHECK(hipEventCreateWithFlags(&h->ev_side_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_comm_done, hipEventDisableTiming));
-        if (cfg->structure != P3D_STRUCTURE_UNET && cfg->structure != P3D_STRUCTURE_CONCAT) throw P3dError("unknown structure");
+        if (cfg->structure < P3D_STRUCTURE_UNET || cfg->structure > P3D_STRUCTURE_GN_P3D) throw P3dError("unknown structure");
         if (cfg->batch < 1) throw P3dError("batch must be >= 1");
         for (int i = 0; i < 3; ++i)
             if (cfg->blocks[i] < 1) throw P3dError("blocks must be >= 1");
         if (cfg->structure == P3D_STRUCTURE_CONCAT) h->build_concat();
+        else if (cfg->structure == P3D_STRUCTURE_GN_P3D) h->build_gn_p3d();
         else h->build_unet();
         h->finalize_build();
         HIPCHECK(hipStreamSynchronize(h->stream));
@@ -1218,6 +1477,14 @@ int p3d_init_params(p3d_handle* h, uint64_t seed) {
                 fo = rf * p->shape[p->shape.size() - 1];
             }
             const float L = (float)std::sqrt(6.0 / (fi + fo));
+            HIPCHECK(p3d_fill_uniform(p->p, p->count, -L, L, seed * 0x9E3779B97F4A7C15ull + idx, h->stream));
+        } else if (p->init == INIT_VS) {
+            // tf.contrib.layers.variance_scaling_initializer(): stddev sqrt(1.3*2/fan_in) (truncated normal in TF;
+            // drawn here as a uniform of the same variance -- parity never depends on the RNG stream, Appendix A.7)
+            double rf = 1;
+            for (size_t i = 0; i + 2 < p->shape.size(); ++i) rf *= (double)p->shape[i];
+            const double fan_in = rf * p->shape[p->shape.size() - 2];
+            const float L = (float)(std::sqrt(1.3 * 2.0 / fan_in) * std::sqrt(3.0));
             HIPCHECK(p3d_fill_uniform(p->p, p->count, -L, L, seed * 0x9E3779B97F4A7C15ull + idx, h->stream));
         } else {
             const float v = p->init == INIT_ONES ? 1.f : 0.f;

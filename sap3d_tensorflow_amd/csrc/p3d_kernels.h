@@ -160,6 +160,58 @@ bool p3d_bn_small_ok(long M, int C);
 hipError_t p3d_bn_small_fwd(const BnSmallArgs& a, hipStream_t s);
 hipError_t p3d_bn_small_bwd(const BnSmallArgs& a, hipStream_t s);
 
+// ---- GroupNorm (gn.hip; reference gn/p3d_gn.py:24-46).  Tables are indexed [n*C + c]. -------------------
+struct GnParams {
+    const float* gamma; const float* beta;       // [C]
+    double* sums;                                // [N][C][2]: forward (sum, sumsq) or backward (sum g, sum g*xhat)
+    float* scale; float* shift; float* mean; float* invstd;     // [N][C]
+    float* coef;                                 // [N][C][3] backward coefficients (k, c1, c2)
+    int C, G;
+};
+struct GnApplyArgs {
+    int mode;                                    // 0,1,3,4,5,6 (gn.hip header)
+    long M; int R; int C;                        // M = N*R rows, R rows per sample
+    const float* y1; int ld1; GnParams g1;
+    const float* y2; int ld2; GnParams g2;       // second GN input (mode 3) or residual / CBAM input (1,4,6)
+    const float* cs; const float* ss;            // mode 6: CBAM channel scale [N][C], spatial scale [M]
+    float* z; int ldz;
+    const float* dz;                             // backward: gradient of z (same stride as z)
+    float* dy1; int lddy1;
+    float* dy2; int lddy2; int acc2;             // mode 3: GN2 input grad; 1,4: residual grad; 6: grad of the CBAM output
+    float drop_scale; float drop_rate; unsigned long long seed;
+};
+hipError_t p3d_gn_stats(const float* y, int ld, int N, int R, int C, double* sums, hipStream_t s);
+hipError_t p3d_gn_finalize(const GnParams& p, int N, int R, float eps, hipStream_t s);
+hipError_t p3d_gn_apply(const GnApplyArgs& a, hipStream_t s);
+hipError_t p3d_gn_bwd_reduce(const GnApplyArgs& a, hipStream_t s);
+hipError_t p3d_gn_bwd_finalize(const GnParams& p, int N, int R, float* dgamma, float* dbeta, hipStream_t s);
+hipError_t p3d_gn_bwd_apply(const GnApplyArgs& a, hipStream_t s);
+
+// ---- CBAM (cbam.hip; reference utils/network.py:198-274 as used at gn/p3d_gn.py:175) --------------------
+struct CbamArgs {
+    const float* x; int ld;                      // block residual [N, D,H,W, C]
+    int N, D, H, W, C, Ch;                       // Ch = C / 8 hidden units
+    const float* k0; const float* b0; const float* k1; const float* b1;     // shared MLP  C->Ch->C
+    const float* k7;                             // [7,7,7,2,1]
+    int chunks;                                  // row chunks per sample of the pooling / backward passes
+    float* part;                                 // [N][chunks][C][3] partial (sum, max, ties-of-max)
+    float* avg; float* mx; float* ties;          // [N][C]
+    float* havg; float* hmx;                     // [N][Ch] post-ReLU hidden activations
+    float* cs;                                   // [N][C]   channel scale = sigmoid(mlp(avg) + mlp(max))
+    float* sp;                                   // [M][2]   channel-mean / channel-max of x*cs
+    float* ss;                                   // [M]      spatial scale = sigmoid(conv7(sp))
+    // backward
+    const float* dout;                           // [M][C] gradient of the CBAM output (dense)
+    float* dpre;                                 // [M]
+    float* dsp;                                  // [M][2]
+    float* dcs_part;                             // [N][chunks][C]
+    float* davg; float* dmx;                     // [N][C] gradients of the pooled vectors
+    float* dx; int lddx; int accx;               // gradient of x
+    float* dk0; float* db0; float* dk1; float* db1; float* dk7;
+};
+hipError_t p3d_cbam_forward(const CbamArgs& a, hipStream_t s);
+hipError_t p3d_cbam_backward(const CbamArgs& a, hipStream_t s);
+
 // ---- max pool (tf.nn.max_pool3d SAME; p3d.py:177,183,189,195) ---------------------------------
 struct PoolArgs {
     const float* x; int N, Di, Hi, Wi, C, ldx;

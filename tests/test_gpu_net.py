@@ -167,3 +167,51 @@ def test_concat_head_forward_backward(cfg, shape):
         floor = 1e-2 * scale
         assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3, n
     s.close()
+
+
+# ---- GroupNorm + CBAM variant (gn/p3d_gn.py inference_p3d; BASELINE.json configs[3]) -------------------------
+GN_SMALL = [
+    (p3d.NetConfig(base=8, blocks=(2, 2, 2)), (2, 16, 32, 32)),
+    (p3d.NetConfig(base=16, blocks=(1, 2, 3)), (1, 16, 48, 32)),
+]
+
+
+def _gn_params(cfg, dtype):
+    from oracle import p3d_gn
+    params = p3d_gn.init_params(1, cfg, dtype=dtype)
+    rng = np.random.default_rng(7)
+    for k, v in params.items():
+        if k.endswith('gamma'):
+            v[:] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith(('beta', '/bias')):
+            v[:] = rng.uniform(-0.3, 0.3, v.shape)
+    return params
+
+
+@pytest.mark.parametrize("cfg,shape", GN_SMALL)
+def test_gn_cbam_forward_backward(cfg, shape):
+    from oracle import p3d_gn
+    p64 = _gn_params(cfg, np.float64)
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    x = p3d.synthetic_clip(0, shape + (3,))
+    y = p3d.synthetic_target(3, shape)
+    s = make_session(cfg, shape, p32, 'gn_p3d')
+    assert [n for n, _, _ in s.variables()] == list(p64)
+    want, g = p3d_gn.forward(p64, x.astype(np.float64), 0.0, False, cfg, np.float64)
+    got = s.forward(x, 0.0, False)
+    for name in ['conv1_custom_bn_relu', 'block0/conv1_bn_relu', 'block0/st', 'block0/out', 'block1/out', 'block2/out',
+                 'conv_concat']:
+        w = g.tape.taps[name].data
+        a = s.activation(name)
+        assert a.shape == w.shape, name
+        assert np.abs(a - w).max() <= 1e-4 * max(np.abs(w).max(), 1.0), name
+    assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)
+    l64, pr64, g64, _ = p3d_gn.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True, cfg, np.float64)
+    l32, _, g32, _ = p3d_gn.loss_and_grads(dict(p32), x, y, 0.0, True, cfg, np.float32)
+    loss, pred = s.backward(x, y, 0.0)
+    assert abs(loss - l64) < 1e-5 * abs(l64)
+    scale = np.median([np.linalg.norm(v) for v in g64.values()])
+    for n, w in g64.items():
+        floor = 1e-2 * scale
+        assert rel_l2(s.get_grad(n), w, floor) <= 5 * rel_l2(g32[n], w, floor) + 2e-3, n
+    s.close()
