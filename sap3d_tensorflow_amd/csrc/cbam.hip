@@ -251,40 +251,59 @@ __global__ __launch_bounds__(256) void bwd_df_kernel(CbamArgs a) {
         a.dcs_part[((long long)n * a.chunks + ch) * a.C + c] = red[c] + red[a.C + c] + red[2 * a.C + c] + red[3 * a.C + c];
 }
 
-// ONE block: loops over samples so the parameter gradients need no atomics.
-__global__ __launch_bounds__(256) void bwd_mlp_kernel(CbamArgs a) {
-    extern __shared__ float sm[];                  // dO[C] dha[Ch] dhm[Ch]
-    float* dO = sm; float* dha = sm + a.C; float* dhm = dha + a.Ch;
-    for (int n = 0; n < a.N; ++n) {
-        for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
-            float s = 0.f;
-            for (int ch = 0; ch < a.chunks; ++ch) s += a.dcs_part[((long long)n * a.chunks + ch) * a.C + c];
-            const float cs = a.cs[(long long)n * a.C + c];
-            dO[c] = s * cs * (1.f - cs);
+// MLP backward, step 1 -- block per sample: dO[n,c] = dcs*cs*(1-cs) (kept in davg as scratch), then the hidden
+// gradients dh_avg / dh_max into dh [n][2][Ch].
+__global__ __launch_bounds__(256) void bwd_mlp1_kernel(CbamArgs a) {
+    extern __shared__ float dO[];                  // [C]
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        float s = 0.f;
+        for (int ch = 0; ch < a.chunks; ++ch) s += a.dcs_part[((long long)n * a.chunks + ch) * a.C + c];
+        const float cs = a.cs[(long long)n * a.C + c];
+        dO[c] = s * cs * (1.f - cs);
+        a.dcs_part[(long long)n * a.chunks * a.C + c] = dO[c];          // chunk 0 slot now holds dO[n,c]
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < a.Ch; j += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < a.C; ++c) s += a.k1[j * a.C + c] * dO[c];
+        const float ha = a.havg[(long long)n * a.Ch + j], hm = a.hmx[(long long)n * a.Ch + j];
+        a.dh[(long long)n * 2 * a.Ch + j] = ha > 0.f ? s : 0.f;
+        a.dh[(long long)n * 2 * a.Ch + a.Ch + j] = hm > 0.f ? s : 0.f;
+    }
+}
+
+// MLP backward, step 2 -- thread per channel c, all samples: gradients of the pooled vectors and of the shared MLP
+// parameters (each (c, j) element is owned by exactly one thread: plain read-modify-write, no atomics).
+__global__ __launch_bounds__(256) void bwd_mlp2_kernel(CbamArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.C) {
+        float db1 = 0.f;
+        for (int n = 0; n < a.N; ++n) {
+            const float* dh = a.dh + (long long)n * 2 * a.Ch;
+            float da = 0.f, dm = 0.f;
+            for (int j = 0; j < a.Ch; ++j) { const float w = a.k0[c * a.Ch + j]; da += w * dh[j]; dm += w * dh[a.Ch + j]; }
+            a.davg[(long long)n * a.C + c] = da; a.dmx[(long long)n * a.C + c] = dm;
+            db1 += 2.f * a.dcs_part[(long long)n * a.chunks * a.C + c];
         }
-        __syncthreads();
+        a.db1[c] += db1;
+        for (int j = 0; j < a.Ch; ++j) {
+            float g0 = 0.f, g1 = 0.f;
+            for (int n = 0; n < a.N; ++n) {
+                const float* dh = a.dh + (long long)n * 2 * a.Ch;
+                g0 += a.avg[(long long)n * a.C + c] * dh[j] + a.mx[(long long)n * a.C + c] * dh[a.Ch + j];
+                g1 += (a.havg[(long long)n * a.Ch + j] + a.hmx[(long long)n * a.Ch + j]) * a.dcs_part[(long long)n * a.chunks * a.C + c];
+            }
+            a.dk0[c * a.Ch + j] += g0;
+            a.dk1[j * a.C + c] += g1;
+        }
+    }
+    if (blockIdx.x == 0)
         for (int j = threadIdx.x; j < a.Ch; j += blockDim.x) {
             float s = 0.f;
-            for (int c = 0; c < a.C; ++c) s += a.k1[j * a.C + c] * dO[c];
-            const float ha = a.havg[(long long)n * a.Ch + j], hm = a.hmx[(long long)n * a.Ch + j];
-            dha[j] = ha > 0.f ? s : 0.f; dhm[j] = hm > 0.f ? s : 0.f;
-            a.db0[j] += dha[j] + dhm[j];
+            for (int n = 0; n < a.N; ++n) s += a.dh[(long long)n * 2 * a.Ch + j] + a.dh[(long long)n * 2 * a.Ch + a.Ch + j];
+            a.db0[j] += s;
         }
-        __syncthreads();
-        for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
-            const float av = a.avg[(long long)n * a.C + c], mv = a.mx[(long long)n * a.C + c];
-            float da = 0.f, dm = 0.f;
-            for (int j = 0; j < a.Ch; ++j) {
-                const float w = a.k0[c * a.Ch + j];
-                da += w * dha[j]; dm += w * dhm[j];
-                a.dk0[c * a.Ch + j] += av * dha[j] + mv * dhm[j];
-                a.dk1[j * a.C + c] += (a.havg[(long long)n * a.Ch + j] + a.hmx[(long long)n * a.Ch + j]) * dO[c];
-            }
-            a.db1[c] += 2.f * dO[c];
-            a.davg[(long long)n * a.C + c] = da; a.dmx[(long long)n * a.C + c] = dm;
-        }
-        __syncthreads();
-    }
 }
 
 // dx += davg/R + dmax * [x == max over the sample's rows] / ties
@@ -328,7 +347,8 @@ hipError_t p3d_cbam_backward(const CbamArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(bwd_spat_conv_kernel, dim3(capped((M + 255) / 256, 4096)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bwd_k7_kernel, dim3(343), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bwd_df_kernel, dim3(a.chunks, a.N), dim3(256), 4 * a.C * sizeof(float), s, a);
-    hipLaunchKernelGGL(bwd_mlp_kernel, dim3(1), dim3(256), (a.C + 2 * a.Ch) * sizeof(float), s, a);
+    hipLaunchKernelGGL(bwd_mlp1_kernel, dim3(a.N), dim3(256), a.C * sizeof(float), s, a);
+    hipLaunchKernelGGL(bwd_mlp2_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bwd_chan_kernel, dim3(capped((M * (a.C >> 2) + 255) / 256, 4096)), dim3(256), 0, s, a);
     return hipGetLastError();
 }

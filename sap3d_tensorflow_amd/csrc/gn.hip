@@ -69,31 +69,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* y, int ld, i
     }
 }
 
-// ---- finalize: thread per (n, group) -> per-(n,c) scale / shift / mean / invstd tables
+// ---- finalize: thread per (n, c); the C/G (a power of two <= 32) lanes of a group fold with shuffles
 __global__ void gn_finalize_kernel(GnParams p, int N, int R, float eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int G = p.G, cg = p.C / G;
-    if (i >= N * G) return;
-    const int n = i / G, g = i - n * G;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < cg; ++k) {
-        s1 += p.sums[((long long)n * p.C + g * cg + k) * 2];
-        s2 += p.sums[((long long)n * p.C + g * cg + k) * 2 + 1];
-    }
+    const int cg = p.C / p.G;
+    const bool ok = i < N * p.C;
+    double s1 = ok ? p.sums[(long long)i * 2] : 0.0, s2 = ok ? p.sums[(long long)i * 2 + 1] : 0.0;
+    for (int o = 1; o < cg; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (!ok) return;
+    const int c = i % p.C;
     const double cnt = (double)R * cg;
     const double mean = s1 / cnt;
     double var = s2 / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
     const double inv = 1.0 / sqrt(var + (double)eps);
-    for (int k = 0; k < cg; ++k) {
-        const int c = g * cg + k;
-        const long long o = (long long)n * p.C + c;
-        const double sc = (double)p.gamma[c] * inv;
-        p.scale[o] = (float)sc;
-        p.shift[o] = (float)((double)p.beta[c] - mean * sc);
-        p.mean[o] = (float)mean;
-        p.invstd[o] = (float)inv;
-    }
+    const double sc = (double)p.gamma[c] * inv;
+    p.scale[i] = (float)sc;
+    p.shift[i] = (float)((double)p.beta[c] - mean * sc);
+    p.mean[i] = (float)mean;
+    p.invstd[i] = (float)inv;
 }
 
 // ---- apply
@@ -189,27 +183,21 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnApplyArgs a) {
     }
 }
 
-// thread per (n, group): fold channels -> per-(n,c) coefficients  dy = k*g - c1 - xhat*c2
+// thread per (n, c): fold gamma-weighted sums over the group's lanes -> coefficients  dy = k*g - c1 - xhat*c2
 __global__ void gn_bwd_finalize_kernel(GnParams p, int N, int R) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int G = p.G, cg = p.C / G;
-    if (i >= N * G) return;
-    const int n = i / G, g = i - n * G;
-    double A = 0.0, B = 0.0;
-    for (int k = 0; k < cg; ++k) {
-        const int c = g * cg + k;
-        A += (double)p.gamma[c] * p.sums[((long long)n * p.C + c) * 2];
-        B += (double)p.gamma[c] * p.sums[((long long)n * p.C + c) * 2 + 1];
-    }
+    const int cg = p.C / p.G;
+    const bool ok = i < N * p.C;
+    const int c = ok ? i % p.C : 0;
+    const double gm = ok ? (double)p.gamma[c] : 0.0;
+    double A = ok ? gm * p.sums[(long long)i * 2] : 0.0, B = ok ? gm * p.sums[(long long)i * 2 + 1] : 0.0;
+    for (int o = 1; o < cg; o <<= 1) { A += __shfl_xor(A, o); B += __shfl_xor(B, o); }
+    if (!ok) return;
     const double cnt = (double)R * cg;
-    for (int k = 0; k < cg; ++k) {
-        const int c = g * cg + k;
-        const long long o = (long long)n * p.C + c;
-        const double inv = p.invstd[o];
-        p.coef[o * 3 + 0] = (float)((double)p.gamma[c] * inv);
-        p.coef[o * 3 + 1] = (float)(inv * A / cnt);
-        p.coef[o * 3 + 2] = (float)(inv * B / cnt);
-    }
+    const double inv = p.invstd[i];
+    p.coef[(long long)i * 3 + 0] = (float)(gm * inv);
+    p.coef[(long long)i * 3 + 1] = (float)(inv * A / cnt);
+    p.coef[(long long)i * 3 + 2] = (float)(inv * B / cnt);
 }
 // thread per channel: dgamma = sum_n sum(g*xhat), dbeta = sum_n sum(g)
 __global__ void gn_bwd_params_kernel(GnParams p, int N, float* dgamma, float* dbeta) {
@@ -274,7 +262,7 @@ hipError_t p3d_gn_stats(const float* y, int ld, int N, int R, int C, double* sum
     return hipGetLastError();
 }
 hipError_t p3d_gn_finalize(const GnParams& p, int N, int R, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * p.G + 255) / 256), dim3(256), 0, s, p, N, R, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * p.C + 255) / 256), dim3(256), 0, s, p, N, R, eps);
     return hipGetLastError();
 }
 
@@ -302,7 +290,7 @@ hipError_t p3d_gn_bwd_reduce(const GnApplyArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t p3d_gn_bwd_finalize(const GnParams& p, int N, int R, float* dgamma, float* dbeta, hipStream_t s) {
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((N * p.G + 255) / 256), dim3(256), 0, s, p, N, R);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((N * p.C + 255) / 256), dim3(256), 0, s, p, N, R);
     hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((p.C + 255) / 256), dim3(256), 0, s, p, N, dgamma, dbeta);
     return hipGetLastError();
 }

@@ -829,7 +829,7 @@ struct p3d_handle {
     int64_t cbam_vec_off(CbamSite* cb) { return (int64_t)cb->x->N * cb->chunks * cb->x->C * 3; }                // avg, mx, ties, cs, davg, dmx: [N][C] each
     int64_t cbam_cs_off(CbamSite* cb) { return cbam_vec_off(cb) + 3 * (int64_t)cb->x->N * cb->x->C; }
     int64_t cbam_h_off(CbamSite* cb) { return cbam_vec_off(cb) + 6 * (int64_t)cb->x->N * cb->x->C; }            // havg, hmx [N][C/8]
-    int64_t cbam_sp_off(CbamSite* cb) { return cbam_h_off(cb) + 2 * (int64_t)cb->x->N * (cb->x->C / 8) + 8; }   // sp [M][2]
+    int64_t cbam_sp_off(CbamSite* cb) { return cbam_h_off(cb) + 4 * (int64_t)cb->x->N * (cb->x->C / 8) + 8; }   // (+ dh [N][2][C/8]) then sp [M][2]
     int64_t cbam_ss_off(CbamSite* cb) { return cbam_sp_off(cb) + 2 * cb->x->rows(); }                          // ss [M]
     int64_t cbam_dpre_off(CbamSite* cb) { return cbam_ss_off(cb) + cb->x->rows(); }                             // dpre [M]
     int64_t cbam_dsp_off(CbamSite* cb) { return cbam_dpre_off(cb) + cb->x->rows(); }                            // dsp [M][2]
@@ -848,7 +848,7 @@ struct p3d_handle {
         a.part = b + cbam_part_off(cb);
         float* v = b + cbam_vec_off(cb);
         a.avg = v; a.mx = v + nc; a.ties = v + 2 * nc; a.cs = v + 3 * nc; a.davg = v + 4 * nc; a.dmx = v + 5 * nc;
-        a.havg = b + cbam_h_off(cb); a.hmx = a.havg + (int64_t)x->N * a.Ch;
+        a.havg = b + cbam_h_off(cb); a.hmx = a.havg + (int64_t)x->N * a.Ch; a.dh = a.hmx + (int64_t)x->N * a.Ch;
         a.sp = b + cbam_sp_off(cb); a.ss = b + cbam_ss_off(cb); a.dpre = b + cbam_dpre_off(cb); a.dsp = b + cbam_dsp_off(cb);
         a.dcs_part = b + cbam_dcs_off(cb);
         a.dout = cb->dout;

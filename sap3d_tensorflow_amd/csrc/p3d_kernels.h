@@ -206,6 +206,7 @@ struct CbamArgs {
     float* dsp;                                  // [M][2]
     float* dcs_part;                             // [N][chunks][C]
     float* davg; float* dmx;                     // [N][C] gradients of the pooled vectors
+    float* dh;                                   // [N][2][Ch] gradients of the hidden activations (avg, max branch)
     float* dx; int lddx; int accx;               // gradient of x
     float* dk0; float* db0; float* dk1; float* db1; float* dk7;
 };

@@ -63,14 +63,19 @@ def test_config1_full_forward_b4(ref_params, training):
 
 
 def test_config2_forward_backward(ref_params):
-    """configs[2] at batch 2 (the oracle finishes in a minute): loss, saliency maps, every gradient,
-    against the float64 oracle."""
+    """configs[2] at batch 2 (the oracle finishes in a minute): loss, saliency maps, every gradient.
+
+    Measured on this graph (199 layers, fp32, B=2): the float32 ORACLE's gradients sit 0.14 (median) / 0.21 (max)
+    rel-L2 from the float64 oracle's -- ReLU / max-pool decisions flipping on 1e-7 perturbations make deep
+    gradients chaotic in fp32 -- while the loss agrees to 3e-7 and the decoder gradients to 1e-3.  So the HIP
+    gradients are held to the float32 oracle's own distance from float64 (x1.5 + 2e-3), tensor by tensor."""
     from sap3d_tensorflow_amd import P3DSession
     x = p3d.synthetic_clip(0, (2, 16, 112, 112, 3))
     y = p3d.synthetic_target(3, (2, 16, 112, 112))
     p64 = {k: v.astype(np.float64) for k, v in ref_params.items()}
     want_loss, want_pred, want_grads, _ = p3d.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True,
                                                              'unet', None, np.float64)
+    _, _, g32, _ = p3d.loss_and_grads(dict(ref_params), x, y, 0.0, True, 'unet')
     s = P3DSession('unet', batch=2)
     s.load(ref_params)
     loss, pred = s.backward(x, y, 0.0)
@@ -78,12 +83,13 @@ def test_config2_forward_backward(ref_params):
     e = np.abs(pred - want_pred) / np.abs(want_pred)
     assert e.max() < 1.5e-3 and e.mean() < 1e-4 and np.quantile(e, 0.999) < 1e-3, (e.max(), e.mean())
     scale = np.median([np.linalg.norm(g) for g in want_grads.values()])
-    errs = {}
+    e_hip, e_o32 = {}, {}
     for n, w in want_grads.items():
-        errs[n] = rel_l2(s.get_grad(n), w, 1e-2 * scale)
-    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    # two fp32 implementations of this 150-layer net differ by ~1e-2 in deep gradients (ReLU / max-pool
-    # decisions flipping on 1e-7 perturbations); see tests/test_oracle_vs_torch.py
-    assert np.median(list(errs.values())) < 2e-2, worst
-    assert worst[0][1] < 0.15, worst
+        e_hip[n] = rel_l2(s.get_grad(n), w, 1e-2 * scale)
+        e_o32[n] = rel_l2(g32[n], w, 1e-2 * scale)
+    worst = sorted(((e_hip[n] / (e_o32[n] + 1e-3), n, e_hip[n], e_o32[n]) for n in e_hip), reverse=True)[:5]
+    assert np.median(list(e_hip.values())) <= 1.5 * np.median(list(e_o32.values())) + 2e-3, worst
+    assert max(e_hip.values()) <= 1.5 * max(e_o32.values()) + 2e-3, worst
+    for n in e_hip:
+        assert e_hip[n] <= 2.5 * e_o32[n] + 2e-2, (n, e_hip[n], e_o32[n])
     s.close()
