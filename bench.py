@@ -44,6 +44,20 @@ def kernel_table(recs):
     return rows
 
 
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+        except Exception:
+            k = None
+        if k:
+            best = k["traffic_bytes_per_launch"]
+    return best
+
+
 def roofline_of(rows):
     """The dominant kernel (largest share of device time) against the roofline that bounds it."""
     top = rows[0]
@@ -53,7 +67,7 @@ def roofline_of(rows):
     else:
         bound, achieved, peak, unit = "hbm", top["gbs"], PEAK_HBM_GBS, "GB/s"
     return dict(kernel=top["kernel"], bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit,
-                frac=round(achieved / peak, 4), traffic=None, launches_per_step=top["launches"],
+                frac=round(achieved / peak, 4), traffic=measured_traffic(top["kernel"]), launches_per_step=top["launches"],
                 avg_launch_us=round(top["avg_us"], 2),
                 flop_per_launch=round(top["flops"] / top["launches"]), bytes_per_launch=round(top["bytes"] / top["launches"]),
                 share_of_device_time=round(top["ms"] / sum(r["ms"] for r in rows), 4))
