@@ -23,8 +23,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BK = 32;
+#ifndef P3D_RING64
+#define P3D_RING64 3
+#endif
 template <int BM, int BN>
-struct Ring { static constexpr int stages = (BM >= 128) ? 2 : 3; };
+struct Ring { static constexpr int stages = (BM >= 128) ? 2 : P3D_RING64; };   // 64x64: deep ring, few steps per K-slice
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
     // LDS destination = wave-uniform base + lane * 16 B
@@ -198,6 +201,35 @@ __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict_
     compute_stage<BM, BN, WT>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
 }
 
+template <int BM, int BN, bool WT, int K>
+struct PrologueLoop {
+    static __device__ __forceinline__ void run(const IgemmArgs& p, float* As, float* Bs, LoadState<BM / 32, BN / 32>& st, int nsteps,
+                                               int kchunks, int wave, int lane) {
+        constexpr int STAGES = Ring<BM, BN>::stages;
+        if constexpr (K < STAGES - 1) {
+            issue_stage<BM, BN, WT>(p, As + K * (BM * BK), Bs + K * (BK * BN), st, nsteps, kchunks, K == 0, wave, lane);
+            PrologueLoop<BM, BN, WT, K + 1>::run(p, As, Bs, st, nsteps, kchunks, wave, lane);
+        }
+    }
+};
+
+template <int BM, int BN, bool WT, int K>
+struct StepLoop {
+    static __device__ __forceinline__ void run(const IgemmArgs& p, float* As, float* Bs, f32x16 (&acc)[BM / 64][BN / 64],
+                                               LoadState<BM / 32, BN / 32>& st, int base, int nsteps, int kchunks, int wave,
+                                               int lane, int wm, int wn) {
+        constexpr int STAGES = Ring<BM, BN>::stages;
+        if constexpr (K < STAGES) {
+            if (base + K < nsteps) {
+                constexpr int D = (K + STAGES - 1) % STAGES;      // stage refilled while stage K is consumed
+                pipe_step<BM, BN, WT>(p, As + D * (BM * BK), Bs + D * (BK * BN), As + K * (BM * BK), Bs + K * (BK * BN), acc, st,
+                                      nsteps, kchunks, wave, lane, wm, wn);
+            }
+            StepLoop<BM, BN, WT, K + 1>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn);
+        }
+    }
+};
+
 template <int BM, int BN, bool WT>
 __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -256,25 +288,11 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
 
     LoadState<LA, BN / 32> st;
     loader_init<BM, BN, WT>(p, st, m0u, Mu, n0, wave, lane, s_begin, kchunks);
-    if (STAGES == 3) {
-        float* A0 = As; float* A1 = As + A_STAGE; float* A2 = As + 2 * A_STAGE;
-        float* B0 = Bs; float* B1 = Bs + B_STAGE; float* B2 = Bs + 2 * B_STAGE;
-        issue_stage<BM, BN, WT>(p, A0, B0, st, nsteps, kchunks, true, wave, lane);
-        issue_stage<BM, BN, WT>(p, A1, B1, st, nsteps, kchunks, false, wave, lane);
-        for (int base = 0; base < nsteps; base += 3) {
-            pipe_step<BM, BN, WT>(p, A2, B2, A0, B0, acc, st, nsteps, kchunks, wave, lane, wm, wn);
-            if (base + 1 < nsteps) pipe_step<BM, BN, WT>(p, A0, B0, A1, B1, acc, st, nsteps, kchunks, wave, lane, wm, wn);
-            if (base + 2 < nsteps) pipe_step<BM, BN, WT>(p, A1, B1, A2, B2, acc, st, nsteps, kchunks, wave, lane, wm, wn);
-        }
-    } else {
-        float* A0 = As; float* A1 = As + A_STAGE;
-        float* B0 = Bs; float* B1 = Bs + B_STAGE;
-        issue_stage<BM, BN, WT>(p, A0, B0, st, nsteps, kchunks, true, wave, lane);
-        for (int base = 0; base < nsteps; base += 2) {
-            pipe_step<BM, BN, WT>(p, A1, B1, A0, B0, acc, st, nsteps, kchunks, wave, lane, wm, wn);
-            if (base + 1 < nsteps) pipe_step<BM, BN, WT>(p, A0, B0, A1, B1, acc, st, nsteps, kchunks, wave, lane, wm, wn);
-        }
-    }
+    // prologue: STAGES-1 steps in flight; then step k computes from stage k % STAGES while refilling the stage
+    // that was consumed one step earlier.  All stage addresses are compile-time constants (StepLoop).
+    PrologueLoop<BM, BN, WT, 0>::run(p, As, Bs, st, nsteps, kchunks, wave, lane);
+    for (int base = 0; base < nsteps; base += STAGES)
+        StepLoop<BM, BN, WT, 0>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn);
     __syncthreads();      // rowOut written above is read below (also when nsteps == 0)
 
     // ---- epilogue ----------------------------------------------------------------------------------
