@@ -125,6 +125,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         sess.train_step_device(0.5, seed=1000 + i)
+    t_enqueued = time.perf_counter() - t0          # host-side launch time (the GPU runs behind it)
     sess.synchronize()
     plane.barrier()
     dt = plane.max_over_ranks(time.perf_counter() - t0)
@@ -151,6 +152,7 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "dropout": 0.5},
             "model_tflops": round(value * FLOP_PER_CLIP_FWD_BWD / 1e12, 2),
             "final_loss": loss,
+            "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
             "roofline": roofline_of(rows),
             "kernels": [dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["ms"], 3), avg_us=round(r["avg_us"], 2),
                              tflops=round(r["tflops"], 2), gbs=round(r["gbs"], 1)) for r in rows[:12]],

@@ -322,6 +322,27 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     float* tile = As;
     wait_vmcnt<0>();
     __syncthreads();
+    if (p.stats) {
+        // per-channel (sum, sumsq) of the stored values straight from the accumulators: lane = column, the 16*TM
+        // registers = rows; fold the two lane halves with a shuffle and the two wave rows through LDS (after the tile).
+        float* sred = tile + BM * LDT;                          // [2][BN][2]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int lc = wn * (BN / 2) + j * 32 + l31;
+            const float bv = (p.bias && (n0 + lc) < p.Nc) ? p.bias[n0 + lc] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (rowOut[r] >= 0) { const float v = acc[i][j][e] + bv; s1 += v; s2 += v * v; }
+                }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (h == 0) { sred[(wm * BN + lc) * 2] = s1; sred[(wm * BN + lc) * 2 + 1] = s2; }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -346,20 +367,17 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
         *reinterpret_cast<float4*>(dst) = v;
     }
     if (p.stats && tid < BN && (n0 + tid) < p.Nc) {
-        const float bv = p.bias ? p.bias[n0 + tid] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-        for (int r = 0; r < BM; ++r)
-            if (rowOut[r] >= 0) { const float v = tile[r * LDT + tid] + bv; s1 += v; s2 += v * v; }
+        const float* sred = tile + BM * LDT;
         double* st = p.stats + (size_t)(blockIdx.x % P3D_STAT_REPLICAS) * 2 * p.Nc;
-        unsafeAtomicAdd(&st[2 * (n0 + tid) + 0], (double)s1);
-        unsafeAtomicAdd(&st[2 * (n0 + tid) + 1], (double)s2);
+        unsafeAtomicAdd(&st[2 * (n0 + tid) + 0], (double)(sred[tid * 2] + sred[(BN + tid) * 2]));
+        unsafeAtomicAdd(&st[2 * (n0 + tid) + 1], (double)(sred[tid * 2 + 1] + sred[(BN + tid) * 2 + 1]));
     }
 }
 
 template <int BM, int BN>
 constexpr size_t smem_bytes() {
     const size_t ring = (size_t)Ring<BM, BN>::stages * (BM * BK + BK * BN) * 4;
-    const size_t tile = (size_t)BM * (BN + 4) * 4;
+    const size_t tile = (size_t)BM * (BN + 4) * 4 + 2 * BN * 2 * 4;       // staged tile + statistics exchange
     return BM * 8 + (ring > tile ? ring : tile);
 }
 

@@ -495,6 +495,51 @@ hipError_t p3d_maxpool_fwd(const PoolArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Non-overlapping windows (k == s, no padding: the temporal pools p3d.py:183,189,195): every input cell belongs to
+// exactly one window, so dx is written (or accumulated) directly -- no atomics, no zero fill.
+__global__ __launch_bounds__(256) void maxpool_bwd_disjoint_kernel(PoolArgs a, int accumulate) {
+    const int c4n = a.C >> 2;
+    const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long pos = i / c4n;
+        const int c = (int)(i - pos * c4n) << 2;
+        const long long opos = pos;
+        const int ow = (int)(pos % a.Wo); pos /= a.Wo;
+        const int oh = (int)(pos % a.Ho); pos /= a.Ho;
+        const int od = (int)(pos % a.Do); const int n = (int)(pos / a.Do);
+        const float4 g = ld4(a.dy + opos * a.lddy + c);
+        const float4 y = ld4(a.y + opos * a.ldy + c);
+        float4 left = g;                       // gradient not yet handed to an earlier (first) maximum
+        bool done[4] = {false, false, false, false};
+        for (int kd = 0; kd < a.kd; ++kd)
+            for (int kh = 0; kh < a.kh; ++kh)
+                for (int kw = 0; kw < a.kw; ++kw) {
+                    const long long ipos = (((long long)n * a.Di + od * a.sd + kd) * a.Hi + oh * a.sh + kh) * a.Wi + ow * a.sw + kw;
+                    const float4 v = ld4(a.x + ipos * a.ldx + c);
+                    float4 d = f4(0.f);
+                    if (!done[0] && v.x == y.x) { d.x = left.x; done[0] = true; }
+                    if (!done[1] && v.y == y.y) { d.y = left.y; done[1] = true; }
+                    if (!done[2] && v.z == y.z) { d.z = left.z; done[2] = true; }
+                    if (!done[3] && v.w == y.w) { d.w = left.w; done[3] = true; }
+                    float* dst = a.dx + ipos * a.lddx + c;
+                    if (accumulate) d = add4(d, ld4(dst));
+                    st4(dst, d);
+                }
+    }
+}
+
+bool p3d_maxpool_disjoint(const PoolArgs& a) {
+    return a.kd == a.sd && a.kh == a.sh && a.kw == a.sw && a.pd == 0 && a.ph == 0 && a.pw == 0 &&
+           a.Do * a.sd == a.Di && a.Ho * a.sh == a.Hi && a.Wo * a.sw == a.Wi;
+}
+
+hipError_t p3d_maxpool_bwd_disjoint(const PoolArgs& a, int accumulate, hipStream_t s) {
+    if ((a.C & 3) || !p3d_maxpool_disjoint(a)) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * (a.C >> 2);
+    hipLaunchKernelGGL(maxpool_bwd_disjoint_kernel, dim3(grid_for(total)), dim3(256), 0, s, a, accumulate);
+    return hipGetLastError();
+}
+
 hipError_t p3d_maxpool_bwd(const PoolArgs& a, hipStream_t s) {
     if (a.C & 3) return hipErrorInvalidValue;
     const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * (a.C >> 2);

@@ -736,8 +736,13 @@ struct p3d_handle {
         const double pool_bytes = op.bytes;
         op.fwd = [=](const Ctx& c) { launch(c, "maxpool_fwd_kernel", 0, pool_bytes, [&]() { return p3d_maxpool_fwd(mk(), c.s); }); };
         op.bwd = [=](const Ctx& c) {
+            const PoolArgs pa = mk();
+            if (p3d_maxpool_disjoint(pa)) {
+                launch(c, "maxpool_bwd_disjoint_kernel", 0, pool_bytes * 2, [&]() { return p3d_maxpool_bwd_disjoint(pa, *xflag, c.s); });
+                return;
+            }
             if (!*xflag) zero_strided(c, x->g, x->ld, x->rows(), x->C);
-            launch(c, "maxpool_bwd_kernel", 0, pool_bytes * 2, [&]() { return p3d_maxpool_bwd(mk(), c.s); });
+            launch(c, "maxpool_bwd_kernel", 0, pool_bytes * 2, [&]() { return p3d_maxpool_bwd(pa, c.s); });
         };
         ops.push_back(op);
         return out;

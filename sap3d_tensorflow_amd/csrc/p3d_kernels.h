@@ -224,6 +224,8 @@ struct PoolArgs {
 };
 hipError_t p3d_maxpool_fwd(const PoolArgs& a, hipStream_t s);
 hipError_t p3d_maxpool_bwd(const PoolArgs& a, hipStream_t s);   // atomically adds into dx
+bool p3d_maxpool_disjoint(const PoolArgs& a);                    // k == s, no padding: windows do not overlap
+hipError_t p3d_maxpool_bwd_disjoint(const PoolArgs& a, int accumulate, hipStream_t s);   // writes / accumulates dx, no atomics
 
 // ---- output head: tf.layers.conv3d_transpose(x, 1, 3, 2, 'same') + sigmoid (p3d.py:217-219) ---
 struct HeadArgs {
