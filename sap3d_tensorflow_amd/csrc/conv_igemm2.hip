@@ -16,7 +16,11 @@
 //
 // fp32 in / fp32 accumulate: v_mfma_f32_32x32x2_f32, exact fp32 at the fp32 peak (157 TFLOP/s).
 #include "p3d_kernels.h"
+#include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -405,7 +409,29 @@ hipError_t launch_t(const IgemmArgs& a, int splits, hipStream_t s) {
 // cannot carry the statistics epilogue or accumulate mode, so the caller must allow it.
 int p3d_igemm2_exp() { static const int v = getenv("P3D_EXP") ? atoi(getenv("P3D_EXP")) : 0; return v; }
 
-P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split) {
+namespace {
+
+// ---- plan cache + on-device autotuning -------------------------------------------------------------------------
+// The best (tile, K-slices) pair depends on how the launch quantises over 256 CUs, on LDS-DMA fill versus MFMA time
+// and on the price of combining partial tiles with atomics; a cost model gets within ~10 %, measuring gets it right.
+// While tuning is on (graph build, p3d_create), the first request for a shape times every candidate on the real
+// buffers (3 runs each, minimum) and caches the winner for the life of the process.
+struct PlanKey {
+    long long M; int K, Nc, ntaps, wT, allow, epi;
+    bool operator<(const PlanKey& o) const {
+        return std::tie(M, K, Nc, ntaps, wT, allow, epi) < std::tie(o.M, o.K, o.Nc, o.ntaps, o.wT, o.allow, o.epi);
+    }
+};
+std::map<PlanKey, P3dIgemmPlan> g_plans;
+std::mutex g_plan_mutex;
+hipStream_t g_tune_stream = nullptr;
+bool g_tuning = false;
+
+const char* plan_name(int bm, int bn) {
+    return bm == 128 ? (bn == 128 ? "igemm2_kernel<128,128>" : "igemm2_kernel<128,64>") : "igemm2_kernel<64,64>";
+}
+
+P3dIgemmPlan heuristic_plan(const IgemmArgs& a, int allow_split) {
     P3dIgemmPlan pl;
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const int kchunks = (a.K + BK - 1) / BK;
@@ -417,9 +443,6 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split) {
     else { pl.bm = 64; pl.bn = 64; }
     pl.splits = 1;
     if (allow_split && steps >= 8) {
-        // measured on MI355X (scratch/tune_igemm.py, stage-2/3 shapes at batch 8): slicing pays below ~150
-        // tiles; ~300 blocks in total and >= 6 steps per slice is the sweet spot, beyond that the fp32
-        // atomics of the partial tiles cost more than the extra CUs bring.
         const long long t = tiles(pl.bm, pl.bn);
         if (t < 150) {
             long long s = (300 + t / 2) / t;
@@ -429,6 +452,65 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split) {
             pl.splits = (int)s;
         }
     }
+    pl.name = plan_name(pl.bm, pl.bn);
+    return pl;
+}
+
+hipError_t launch_plan(const IgemmArgs& a, const P3dIgemmPlan& pl, hipStream_t s);
+
+P3dIgemmPlan measure_plan(const IgemmArgs& a0, int allow_split) {
+    const int kchunks = (a0.K + BK - 1) / BK;
+    const int steps = a0.ntaps * kchunks;
+    const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    P3dIgemmPlan best = heuristic_plan(a0, allow_split);
+    float best_ms = 1e30f;
+    for (auto& t : tiles) {
+        if (t[1] == 128 && a0.Nc <= 64) continue;
+        for (int sp : splits) {
+            if (sp > 1 && (!allow_split || sp > steps / 2)) break;
+            P3dIgemmPlan pl; pl.bm = t[0]; pl.bn = t[1]; pl.splits = sp; pl.name = plan_name(t[0], t[1]);
+            IgemmArgs a = a0;
+            if (sp > 1) { a.stats = nullptr; a.accum = 0; }
+            float ms_min = 1e30f;
+            bool ok = true;
+            for (int rep = 0; rep < 4 && ok; ++rep) {
+                hipEventRecord(e0, g_tune_stream);
+                ok = launch_plan(a, pl, g_tune_stream) == hipSuccess;
+                hipEventRecord(e1, g_tune_stream);
+                if (hipEventSynchronize(e1) != hipSuccess) ok = false;
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < ms_min) ms_min = ms;
+            }
+            if (ok && ms_min < best_ms * 0.97f) { best_ms = ms_min; best = pl; }
+        }
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return best;
+}
+
+}  // namespace
+
+void p3d_tune_begin(hipStream_t s) { std::lock_guard<std::mutex> g(g_plan_mutex); g_tune_stream = s; g_tuning = getenv("P3D_NO_TUNE") == nullptr; }
+void p3d_tune_end() { std::lock_guard<std::mutex> g(g_plan_mutex); g_tuning = false; }
+
+// Tile / K-slice choice for one launch.  Slicing needs a zeroed output and cannot carry the statistics epilogue
+// or accumulate mode, so the caller must allow it.
+P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split) {
+    const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
+    const PlanKey key{M, a.K, a.Nc, a.ntaps, a.wT, allow_split ? 1 : 0, (a.stats ? 1 : 0) | (a.accum ? 2 : 0) | (a.bias ? 4 : 0)};
+    std::lock_guard<std::mutex> g(g_plan_mutex);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    P3dIgemmPlan pl = heuristic_plan(a, allow_split);
+    if (g_tuning && a.x && a.y && a.w && a.zeros && a.ntaps > 0 && M > 0) {
+        pl = measure_plan(a, allow_split);
+        g_plans[key] = pl;
+    }
+    const int steps = a.ntaps * ((a.K + BK - 1) / BK);
     if (const char* e = getenv("P3D_SPLITS")) {            // tuning override (scratch/tune_igemm.py)
         const int v = atoi(e);
         if (v >= 1 && allow_split && v <= steps) pl.splits = v;
@@ -437,11 +519,14 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split) {
         const int v = atoi(e);
         if (v == 0) { pl.bm = 64; pl.bn = 64; } else if (v == 1) { pl.bm = 128; pl.bn = 64; } else if (v == 2) { pl.bm = 128; pl.bn = 128; }
     }
-    pl.name = pl.bm == 128 ? (pl.bn == 128 ? "igemm2_kernel<128,128>" : "igemm2_kernel<128,64>") : "igemm2_kernel<64,64>";
+    pl.name = plan_name(pl.bm, pl.bn);
     return pl;
 }
 
-hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) {
+hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& pl, hipStream_t s) { return launch_plan(a, pl, s); }
+
+namespace {
+hipError_t launch_plan(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) {
     IgemmArgs a = a0;
     a.exp = p3d_igemm2_exp();
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
@@ -456,3 +541,4 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStr
     if (pl.bm == 128 && pl.bn == 64) return launch_t<128, 64>(a, pl.splits, s);
     return launch_t<64, 64>(a, pl.splits, s);
 }
+}  // namespace

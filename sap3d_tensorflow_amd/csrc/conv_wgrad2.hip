@@ -6,13 +6,15 @@
 // k = position.  Padded / out-of-range rows come from a zero page.  The position range is split
 // over gridDim.y; partial tiles are added with fp32 atomics (dW is zeroed once per step).
 #include "p3d_kernels.h"
+#include <algorithm>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
 constexpr int BKM = 32;
-constexpr int STAGES = 3;
+template <int BM>
+struct WRing { static constexpr int stages = (BM >= 128) ? 2 : 3; };   // 128x128: 64 KB -> two blocks per CU
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -126,7 +128,7 @@ __device__ __forceinline__ void pipe_step(const WgradArgs& p, const P3dTap tap, 
                                           bool do_bias, WState<BM / 32, BN / 32>& st, unsigned me, int wave, int lane, int wm,
                                           int wn) {
     constexpr int LPS = BM / 32 + BN / 32;
-    wait_vmcnt<LPS>();
+    wait_vmcnt<(WRing<BM>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();
     issue_stage<BM, BN>(p, tap, a_dst, b_dst, st, me, wave, lane);
     compute_stage<BM, BN>(a_src, b_src, acc, bsum, do_bias, wm, wn, lane >> 5, lane & 31);
@@ -136,6 +138,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void wgrad2_kernel(const WgradArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_STAGE = BKM * BM, B_STAGE = BKM * BN;
+    constexpr int STAGES = WRing<BM>::stages;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);
     float* Bs = As + STAGES * A_STAGE;
@@ -174,14 +177,24 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WgradArgs p) {
     WState<BM / 32, BN / 32> st;
     wloader_init<BM, BN>(p, st, (unsigned)ms, k0, n0, wave, lane);
     const unsigned meu = (unsigned)me;
-    float* A0 = As; float* A1 = As + A_STAGE; float* A2 = As + 2 * A_STAGE;
-    float* B0 = Bs; float* B1 = Bs + B_STAGE; float* B2 = Bs + 2 * B_STAGE;
-    issue_stage<BM, BN>(p, tap, A0, B0, st, meu, wave, lane);
-    issue_stage<BM, BN>(p, tap, A1, B1, st, meu, wave, lane);
-    for (int base = 0; base < nsteps; base += STAGES) {
-        pipe_step<BM, BN>(p, tap, A2, B2, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
-        if (base + 1 < nsteps) pipe_step<BM, BN>(p, tap, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
-        if (base + 2 < nsteps) pipe_step<BM, BN>(p, tap, A1, B1, A2, B2, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+    if (STAGES == 3) {
+        float* A0 = As; float* A1 = As + A_STAGE; float* A2 = As + 2 * A_STAGE;
+        float* B0 = Bs; float* B1 = Bs + B_STAGE; float* B2 = Bs + 2 * B_STAGE;
+        issue_stage<BM, BN>(p, tap, A0, B0, st, meu, wave, lane);
+        issue_stage<BM, BN>(p, tap, A1, B1, st, meu, wave, lane);
+        for (int base = 0; base < nsteps; base += 3) {
+            pipe_step<BM, BN>(p, tap, A2, B2, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            if (base + 1 < nsteps) pipe_step<BM, BN>(p, tap, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            if (base + 2 < nsteps) pipe_step<BM, BN>(p, tap, A1, B1, A2, B2, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+        }
+    } else {
+        float* A0 = As; float* A1 = As + A_STAGE;
+        float* B0 = Bs; float* B1 = Bs + B_STAGE;
+        issue_stage<BM, BN>(p, tap, A0, B0, st, meu, wave, lane);
+        for (int base = 0; base < nsteps; base += 2) {
+            pipe_step<BM, BN>(p, tap, A1, B1, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            if (base + 1 < nsteps) pipe_step<BM, BN>(p, tap, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+        }
     }
     __syncthreads();
 
@@ -202,7 +215,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WgradArgs p) {
 
 template <int BM, int BN>
 hipError_t launch_t(const WgradArgs& a, long long tiles, hipStream_t s) {
-    constexpr size_t sm = (size_t)STAGES * BKM * (BM + BN) * 4;
+    constexpr size_t sm = (size_t)WRing<BM>::stages * BKM * (BM + BN) * 4;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute((const void*)wgrad2_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -212,27 +225,36 @@ hipError_t launch_t(const WgradArgs& a, long long tiles, hipStream_t s) {
     return hipGetLastError();
 }
 
-struct WPlan { int tile; long long tiles; int ks; };
+struct WPlan { int tile; long long tiles; int ks; double cost; };
+// Pick the tile and the number of position-range splits with a small cost model: blocks run in rounds of
+// `slots` (256 CUs x resident blocks per CU), a round lasts (steps per block + fixed overhead) step-times, and a
+// 128x128 step is ~3.2x a 64x64 step (4x the MFMAs, better LDS-DMA efficiency).  This avoids e.g. 540 blocks on
+// 512 slots (a second round with 28 blocks).
 WPlan plan(const WgradArgs& a) {
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const long long steps = (M + BKM - 1) / BKM;
-    auto mk = [&](int T) {
+    auto best_for = [&](int T) {
         WPlan w;
-        w.tile = T;
+        w.tile = T; w.ks = 1; w.cost = 1e300;
         w.tiles = (long long)a.ntaps * ((a.K + T - 1) / T) * ((a.Nc + T - 1) / T);
-        long long ks = (512 + w.tiles - 1) / w.tiles;
-        const long long kmax = steps / 4 > 0 ? steps / 4 : 1;      // >= 4 steps per block
-        if (ks > kmax) ks = kmax;
-        if (ks < 1) ks = 1;
-        if (ks > 65535) ks = 65535;
-        w.ks = (int)ks;
+        const long long slots = 256 * (T == 128 ? 2 : 3);
+        const double step_time = T == 128 ? 3.2 : 1.0, overhead = T == 128 ? 8.0 : 8.0;
+        const long long kmax = std::max<long long>(1, std::min<long long>(steps / 4, 4096));
+        for (long long ks = 1; ks <= kmax; ks = ks < 16 ? ks + 1 : ks + ks / 8) {
+            const long long blocks = w.tiles * ks;
+            const long long rounds = (blocks + slots - 1) / slots;
+            const double per_block = (double)((steps + ks - 1) / ks) + overhead;
+            const double cost = rounds * per_block * step_time;
+            if (cost < w.cost * 0.98) { w.cost = cost; w.ks = (int)std::min<long long>(ks, 65535); }
+        }
         return w;
     };
+    const WPlan small = best_for(64);
     if (a.K >= 128 && a.Nc >= 128) {
-        const WPlan big = mk(128);
-        if (big.tiles * big.ks >= 256) return big;
+        const WPlan big = best_for(128);
+        if (big.cost <= small.cost) return big;
     }
-    return mk(64);
+    return small;
 }
 
 }  // namespace

@@ -1205,7 +1205,24 @@ struct p3d_handle {
         bnbuf = dalloc<float>(bnbuf_count);
         for (auto& f : late_bind) f();
         late_bind.clear();
+        tune_plans();
         plan_zero_arenas();
+    }
+
+    // One forward + backward over garbage data with the kernels' autotuners switched on: every distinct conv
+    // shape of the graph gets its tile / split decided by measurement before the zero arenas (which depend on
+    // those decisions) are laid out.  Parameters and moving statistics are not touched.
+    void tune_plans() {
+        p3d_tune_begin(stream);
+        Ctx c; c.training = true; c.s = stream;
+        HIPCHECK(hipMemsetAsync(stats_arena, 0, (size_t)stats_count * sizeof(double), c.s));
+        for (auto& op : ops) op.fwd(c);
+        HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), c.s));
+        for (int i = (int)ops.size() - 1; i >= 0; --i) ops[i].bwd(c);
+        HIPCHECK(hipStreamSynchronize(c.s));
+        p3d_tune_end();
+        HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
+        HIPCHECK(hipStreamSynchronize(c.s));
     }
 
     // Dry-run forward and backward once: every dense buffer an op would zero-fill before adding into it

@@ -83,6 +83,10 @@ extern "C++" {
 hipError_t p3d_launch_igemm(const IgemmArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad(const WgradArgs& a, hipStream_t s);
 P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split);
+// Autotuning window (graph build): inside it, the first plan request for a new shape is decided by timing the
+// candidates on stream `s` with the caller's real buffers; outside it, a heuristic answers for unseen shapes.
+void p3d_tune_begin(hipStream_t s);
+void p3d_tune_end();
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipStream_t s);
 const char* p3d_igemm_variant(const IgemmArgs& a);     // kernel symbol the launcher will pick
 const char* p3d_wgrad_variant(const WgradArgs& a);
