@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Python-3 counterpart of the reference trainer (/root/reference/train.py) on libp3dhip.
+
+Same flags (train.py:21-45), same step semantics (train.py:217-218: dropout 0.5, training=True, Adam lr,
+Smooth-L1 sum), same periodic eval forward (train.py:225-226) and checkpoint cadence (train.py:266-267).  The
+dataset loaders (dataflow.py, tensorpack, cv2) are out of scope: clips come either from
+`--data clips.npz` (arrays x [N,16,112,112,3] already normalised like dataflow.py:204-208, y [N,16,112,112]) or
+are synthetic with the loader's value law.  Checkpoints are .npz files keyed by the TF variable names of
+train.py:180-185 (trainables + BN moving statistics)."""
+import argparse
+import datetime
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def get_arguments():
+    p = argparse.ArgumentParser(description="P3D saliency trainer (MI355X-native)")
+    p.add_argument("--normalization", type=str, default="bn", help="bn -> p3d.py graphs, gn -> gn/p3d_gn.py inference_p3d")
+    p.add_argument("--structure", type=str, default="unet", help="unet | concat (train.py:149-154)")
+    p.add_argument("--batch", type=int, default=2)
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--epoch", type=int, default=1)
+    p.add_argument("--gpu", type=str, default="0")
+    p.add_argument("--pretrain", type=str, default="", help="checkpoint .npz to resume from (train.py:204-210)")
+    p.add_argument("--saveiter", type=int, default=1000)
+    p.add_argument("--validiter", type=int, default=1000)
+    p.add_argument("--plotiter", type=int, default=1000)
+    p.add_argument("--info", type=str, default="run")
+    p.add_argument("--data", type=str, default="", help="npz with x, y; empty = synthetic clips")
+    p.add_argument("--steps", type=int, default=20, help="steps per epoch when synthetic")
+    return p.parse_args()
+
+
+def batches(args, rng):
+    from oracle import p3d as law      # only the synthetic-input law (dataflow.py:204-208)
+    if args.data:
+        d = np.load(args.data)
+        x, y = d["x"].astype(np.float32), d["y"].astype(np.float32)
+        for e in range(args.epoch):
+            order = rng.permutation(len(x))
+            for i in range(0, len(x) - args.batch + 1, args.batch):
+                idx = order[i:i + args.batch]
+                yield x[idx], y[idx]
+    else:
+        for s in range(args.epoch * args.steps):
+            yield (law.synthetic_clip(s, (args.batch, 16, 112, 112, 3)), law.synthetic_target(10_000 + s, (args.batch, 16, 112, 112)))
+
+
+def main():
+    args = get_arguments()
+    from sap3d_tensorflow_amd import P3DSession
+    structure = "gn_p3d" if args.normalization == "gn" else args.structure
+    sess = P3DSession(structure, batch=args.batch, device=int(args.gpu), seed=0)      # graph + global_variables_initializer
+    sess.set_adam(args.lr)
+    model_dir = os.path.join("model", args.info)
+    os.makedirs(model_dir, exist_ok=True)
+    if args.pretrain:
+        print(args.pretrain, "Using this model to retrain...")
+        sess.load(dict(np.load(args.pretrain)))
+    print("Start training")
+    step = 0
+    for xs, ys in batches(args, np.random.default_rng(0)):
+        step += 1
+        loss = sess.train_step(xs, ys, dropout=0.5, seed=step)                      # train.py:217-218
+        if step < 10 or step % args.plotiter == 0:
+            image = sess.forward(xs, dropout=0.0, training=False)                   # train.py:225-226
+            print("Datetime", datetime.datetime.now().isoformat()[:-7], "Training step:", step,
+                  float(np.sum(image[0, -1]) * 255.0), float(np.sum(ys[0][-1]) * 255.0), "Training Loss", loss)
+        if step % args.saveiter == 0:
+            np.savez(os.path.join(model_dir, "p3d_%d.npz" % step), **sess.save())  # train.py:266-267
+    print("Training Finished!")
+    sess.close()
+
+
+if __name__ == "__main__":
+    main()
