@@ -53,11 +53,24 @@ __global__ __launch_bounds__(256) void chan_mlp_kernel(CbamArgs a) {
         a.avg[(long long)n * a.C + c] = avg[c]; a.mx[(long long)n * a.C + c] = m; a.ties[(long long)n * a.C + c] = t;
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < a.Ch; j += blockDim.x) {
-        float sa = a.b0[j], sb = a.b0[j];
-        for (int c = 0; c < a.C; ++c) { const float w = a.k0[c * a.Ch + j]; sa += avg[c] * w; sb += mx[c] * w; }
-        ha[j] = fmaxf(sa, 0.f); hm[j] = fmaxf(sb, 0.f);
-        a.havg[(long long)n * a.Ch + j] = ha[j]; a.hmx[(long long)n * a.Ch + j] = hm[j];
+    {   // hidden layer: thread = (unit j, slice of the C inputs); slices folded through LDS
+        float* part = hm + a.Ch;                        // [parts][Ch][2]
+        const int parts = blockDim.x / a.Ch > 0 ? blockDim.x / a.Ch : 1;
+        const int j = threadIdx.x % a.Ch, pt = threadIdx.x / a.Ch;
+        if (pt < parts) {
+            const int per = (a.C + parts - 1) / parts;
+            const int c0 = pt * per, c1 = min(a.C, c0 + per);
+            float sa = 0.f, sb = 0.f;
+            for (int c = c0; c < c1; ++c) { const float w = a.k0[c * a.Ch + j]; sa += avg[c] * w; sb += mx[c] * w; }
+            part[(pt * a.Ch + j) * 2] = sa; part[(pt * a.Ch + j) * 2 + 1] = sb;
+        }
+        __syncthreads();
+        if (threadIdx.x < a.Ch) {
+            float sa = a.b0[j], sb = a.b0[j];
+            for (int q = 0; q < parts; ++q) { sa += part[(q * a.Ch + j) * 2]; sb += part[(q * a.Ch + j) * 2 + 1]; }
+            ha[j] = fmaxf(sa, 0.f); hm[j] = fmaxf(sb, 0.f);
+            a.havg[(long long)n * a.Ch + j] = ha[j]; a.hmx[(long long)n * a.Ch + j] = hm[j];
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
@@ -168,32 +181,41 @@ __global__ __launch_bounds__(256) void bwd_spat_conv_kernel(CbamArgs a) {
     }
 }
 
-// dK7[tap][ch] = sum_pos sp[pos + tap - 3][ch] * dpre[pos].  block per tap; threads stride over positions.
-__global__ __launch_bounds__(256) void bwd_k7_kernel(CbamArgs a) {
-    __shared__ float r0[256], r1[256];
-    const int tap = blockIdx.x;
-    const int kd = tap / 49, kh = (tap / 7) % 7, kk = tap % 7;
+// dK7[tap][ch] = sum_pos sp[pos + tap - 3][ch] * dpre[pos].  Block = a chunk of 64 positions (coordinates and dpre
+// staged in LDS once), thread = one tap (343 of 384 threads); one atomic pair per (block, tap).
+__global__ __launch_bounds__(384) void bwd_k7_kernel(CbamArgs a) {
+    __shared__ int pd[64], ph[64], pw[64], pn[64];
+    __shared__ float pg[64];
     const int R = a.D * a.H * a.W;
     const long long M = (long long)a.N * R;
+    const int tap = threadIdx.x;
+    const int kd = tap / 49 - 3, kh = (tap / 7) % 7 - 3, kk = tap % 7 - 3;
     float a0 = 0.f, a1 = 0.f;
-    for (long long pos = threadIdx.x; pos < M; pos += blockDim.x) {
-        long long t = pos;
-        const int w = (int)(t % a.W); t /= a.W;
-        const int h = (int)(t % a.H); t /= a.H;
-        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
-        const int id = d + kd - 3, ih = h + kh - 3, iw = w + kk - 3;
-        if ((unsigned)id >= (unsigned)a.D || (unsigned)ih >= (unsigned)a.H || (unsigned)iw >= (unsigned)a.W) continue;
-        const float g = a.dpre[pos];
-        const float* sp = a.sp + ((((long long)n * a.D + id) * a.H + ih) * a.W + iw) * 2;
-        a0 += g * sp[0]; a1 += g * sp[1];
-    }
-    r0[threadIdx.x] = a0; r1[threadIdx.x] = a1;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+    for (long long base = (long long)blockIdx.x * 64; base < M; base += (long long)gridDim.x * 64) {
         __syncthreads();
+        if (threadIdx.x < 64) {
+            const long long pos = base + threadIdx.x;
+            if (pos < M) {
+                long long t = pos;
+                pw[threadIdx.x] = (int)(t % a.W); t /= a.W;
+                ph[threadIdx.x] = (int)(t % a.H); t /= a.H;
+                pd[threadIdx.x] = (int)(t % a.D); pn[threadIdx.x] = (int)(t / a.D);
+                pg[threadIdx.x] = a.dpre[pos];
+            } else { pn[threadIdx.x] = -1; pg[threadIdx.x] = 0.f; pd[threadIdx.x] = ph[threadIdx.x] = pw[threadIdx.x] = 0; }
+        }
+        __syncthreads();
+        if (tap < 343) {
+            for (int i = 0; i < 64; ++i) {
+                const int n = pn[i];
+                const int id = pd[i] + kd, ih = ph[i] + kh, iw = pw[i] + kk;
+                if (n >= 0 && (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
+                    const float* sp = a.sp + ((((long long)n * a.D + id) * a.H + ih) * a.W + iw) * 2;
+                    a0 += pg[i] * sp[0]; a1 += pg[i] * sp[1];
+                }
+            }
+        }
     }
-    if (threadIdx.x == 0) { unsafeAtomicAdd(a.dk7 + tap * 2, r0[0]); unsafeAtomicAdd(a.dk7 + tap * 2 + 1, r1[0]); }
+    if (tap < 343) { unsafeAtomicAdd(a.dk7 + tap * 2, a0); unsafeAtomicAdd(a.dk7 + tap * 2 + 1, a1); }
 }
 
 // grid (chunks, N), wave per position inside the chunk: df = dout*ss + dmean/C + dmax*[f == max]/ties;
@@ -273,29 +295,21 @@ __global__ __launch_bounds__(256) void bwd_mlp1_kernel(CbamArgs a) {
     }
 }
 
-// MLP backward, step 2 -- thread per channel c, all samples: gradients of the pooled vectors and of the shared MLP
-// parameters (each (c, j) element is owned by exactly one thread: plain read-modify-write, no atomics).
-__global__ __launch_bounds__(256) void bwd_mlp2_kernel(CbamArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < a.C) {
-        float db1 = 0.f;
-        for (int n = 0; n < a.N; ++n) {
-            const float* dh = a.dh + (long long)n * 2 * a.Ch;
-            float da = 0.f, dm = 0.f;
-            for (int j = 0; j < a.Ch; ++j) { const float w = a.k0[c * a.Ch + j]; da += w * dh[j]; dm += w * dh[a.Ch + j]; }
-            a.davg[(long long)n * a.C + c] = da; a.dmx[(long long)n * a.C + c] = dm;
-            db1 += 2.f * a.dcs_part[(long long)n * a.chunks * a.C + c];
-        }
-        a.db1[c] += db1;
-        for (int j = 0; j < a.Ch; ++j) {
-            float g0 = 0.f, g1 = 0.f;
-            for (int n = 0; n < a.N; ++n) {
-                const float* dh = a.dh + (long long)n * 2 * a.Ch;
-                g0 += a.avg[(long long)n * a.C + c] * dh[j] + a.mx[(long long)n * a.C + c] * dh[a.Ch + j];
-                g1 += (a.havg[(long long)n * a.Ch + j] + a.hmx[(long long)n * a.Ch + j]) * a.dcs_part[(long long)n * a.chunks * a.C + c];
-            }
-            a.dk0[c * a.Ch + j] += g0;
-            a.dk1[j * a.C + c] += g1;
+// MLP backward, step 2a -- thread per (n, c): gradients of the pooled vectors; block 0 also folds db0, and the
+// threads of sample 0 fold db1.
+__global__ __launch_bounds__(256) void bwd_mlp2a_kernel(CbamArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.N * a.C) {
+        const int n = i / a.C, c = i - n * a.C;
+        const float* dh = a.dh + (long long)n * 2 * a.Ch;
+        const float* w = a.k0 + (long long)c * a.Ch;
+        float da = 0.f, dm = 0.f;
+        for (int j = 0; j < a.Ch; ++j) { da += w[j] * dh[j]; dm += w[j] * dh[a.Ch + j]; }
+        a.davg[i] = da; a.dmx[i] = dm;
+        if (n == 0) {
+            float s = 0.f;
+            for (int m = 0; m < a.N; ++m) s += a.dcs_part[(long long)m * a.chunks * a.C + c];
+            a.db1[c] += 2.f * s;
         }
     }
     if (blockIdx.x == 0)
@@ -304,6 +318,20 @@ __global__ __launch_bounds__(256) void bwd_mlp2_kernel(CbamArgs a) {
             for (int n = 0; n < a.N; ++n) s += a.dh[(long long)n * 2 * a.Ch + j] + a.dh[(long long)n * 2 * a.Ch + a.Ch + j];
             a.db0[j] += s;
         }
+}
+// step 2b -- thread per weight element (c, j): dk0[c][j], dk1[j][c] (each owned by one thread: plain RMW)
+__global__ __launch_bounds__(256) void bwd_mlp2b_kernel(CbamArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.C * a.Ch) return;
+    const int c = i / a.Ch, j = i - c * a.Ch;
+    float g0 = 0.f, g1 = 0.f;
+    for (int n = 0; n < a.N; ++n) {
+        const float* dh = a.dh + (long long)n * 2 * a.Ch;
+        g0 += a.avg[(long long)n * a.C + c] * dh[j] + a.mx[(long long)n * a.C + c] * dh[a.Ch + j];
+        g1 += (a.havg[(long long)n * a.Ch + j] + a.hmx[(long long)n * a.Ch + j]) * a.dcs_part[(long long)n * a.chunks * a.C + c];
+    }
+    a.dk0[i] += g0;
+    a.dk1[(long long)j * a.C + c] += g1;
 }
 
 // dx += davg/R + dmax * [x == max over the sample's rows] / ties
@@ -334,7 +362,7 @@ hipError_t p3d_cbam_forward(const CbamArgs& a, hipStream_t s) {
     if ((a.C & 3) || a.C > 1024 || a.Ch < 1 || a.chunks < 1) return hipErrorInvalidValue;
     const long long M = (long long)a.N * a.D * a.H * a.W;
     hipLaunchKernelGGL(chan_pool_kernel, dim3(a.chunks, a.N), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chan_mlp_kernel, dim3(a.N), dim3(256), (2 * a.C + 2 * a.Ch) * sizeof(float), s, a);
+    hipLaunchKernelGGL(chan_mlp_kernel, dim3(a.N), dim3(256), (2 * a.C + 2 * a.Ch + 2 * 256) * sizeof(float), s, a);
     hipLaunchKernelGGL(spat_pool_kernel, dim3(capped((M + 3) / 4, 8192)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(spat_conv_kernel, dim3(capped((M + 255) / 256, 4096)), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -345,10 +373,11 @@ hipError_t p3d_cbam_backward(const CbamArgs& a, hipStream_t s) {
     const long long M = (long long)a.N * a.D * a.H * a.W;
     hipLaunchKernelGGL(bwd_dpre_kernel, dim3(capped((M + 3) / 4, 8192)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bwd_spat_conv_kernel, dim3(capped((M + 255) / 256, 4096)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(bwd_k7_kernel, dim3(343), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bwd_k7_kernel, dim3(capped((M + 63) / 64, 1024)), dim3(384), 0, s, a);
     hipLaunchKernelGGL(bwd_df_kernel, dim3(a.chunks, a.N), dim3(256), 4 * a.C * sizeof(float), s, a);
     hipLaunchKernelGGL(bwd_mlp1_kernel, dim3(a.N), dim3(256), a.C * sizeof(float), s, a);
-    hipLaunchKernelGGL(bwd_mlp2_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bwd_mlp2a_kernel, dim3((a.N * a.C + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bwd_mlp2b_kernel, dim3((a.C * a.Ch + 255) / 256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bwd_chan_kernel, dim3(capped((M * (a.C >> 2) + 255) / 256, 4096)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
