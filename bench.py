@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU (BASELINE.json config: batch 8 per MI355X)")
     ap.add_argument("--structure", default="unet", choices=["unet", "concat", "gn_p3d"],
                     help="graph to time (default: the BASELINE.json headline, p3d_unet)")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=112, help="clip height = width (BASELINE configs[4] uses 32 frames of 224)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--dump-launches", default=None, help="write every launch record of the profiled step to this CSV")
@@ -111,11 +113,12 @@ def main():
     from oracle import p3d as oracle          # synthetic-input law only (dataflow.py:204-208)
 
     B = args.batch
-    sess = P3DSession(args.structure, batch=B, device=local_rank, world_size=world, rank=rank, seed=1)
+    T, S = args.frames, args.size
+    sess = P3DSession(args.structure, batch=B, frames=T, height=S, width=S, device=local_rank, world_size=world, rank=rank, seed=1)
     if world > 1:
         sess.comm_init(plane.share_from_rank0(P3DSession.comm_unique_id))
-    x = oracle.synthetic_clip(rank, (B, 16, 112, 112, 3))
-    y = oracle.synthetic_target(3 + rank, (B, 16, 112, 112))
+    x = oracle.synthetic_clip(rank, (B, T, S, S, 3))
+    y = oracle.synthetic_target(3 + rank, (B, T, S, S))
     sess.upload(x, y)
 
     for i in range(args.warmup):
@@ -145,19 +148,19 @@ def main():
             "metric": "clips/s (16x112x112 fwd+bwd)", "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s train step: fwd + Smooth-L1 + bwd + Adam, 16x112x112x3 clips, batch %d per GPU (%s)" %
+            "config": {"workload": "%s train step: fwd + Smooth-L1 + bwd + Adam, %dx%dx%dx3 clips, batch %d per GPU (%s)" %
                                    ({"unet": "p3d_unet (P3D-199 encoder + unet decoder)", "concat": "p3d_concat",
-                                     "gn_p3d": "p3d_gn.inference_p3d (GroupNorm + CBAM)"}[args.structure], B,
+                                     "gn_p3d": "p3d_gn.inference_p3d (GroupNorm + CBAM)"}[args.structure], T, S, S, B,
                                     "BASELINE.json configs[2]" if args.structure == "unet" else "BASELINE.json configs[3] graph, 1 GPU"),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "dropout": 0.5},
-            "model_tflops": round(value * FLOP_PER_CLIP_FWD_BWD / 1e12, 2),
+            "model_tflops": round(value * FLOP_PER_CLIP_FWD_BWD * (T / 16.0) * (S / 112.0) ** 2 / 1e12, 2) if args.structure == "unet" else None,
             "final_loss": loss,
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
             "roofline": roofline_of(rows),
             "kernels": [dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["ms"], 3), avg_us=round(r["avg_us"], 2),
                              tflops=round(r["tflops"], 2), gbs=round(r["gbs"], 1)) for r in rows[:12]],
         }
-        if world == 1 and not args.no_cpu_baseline and args.structure == "unet":
+        if world == 1 and not args.no_cpu_baseline and args.structure == "unet" and (T, S) == (16, 112):
             out["cpu_baseline"] = cpu_baseline(1)
         if args.kernels:
             for r in rows:
