@@ -73,6 +73,25 @@ def roofline_of(rows):
                 share_of_device_time=round(top["ms"] / sum(r["ms"] for r in rows), 4))
 
 
+def usable_cores():
+    """Host cores this process may really use: CPU affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(batch=1):
     """The oracle (numpy restatement, OpenBLAS threads) on one train step of `batch` clips."""
     from oracle import p3d as oracle
@@ -80,10 +99,18 @@ def cpu_baseline(batch=1):
     x = oracle.synthetic_clip(0, (batch, 16, 112, 112, 3))
     y = oracle.synthetic_target(3, (batch, 16, 112, 112))
     state = {"t": 0, "m": {}, "v": {}}
+    cores = usable_cores()
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=cores)
+    except Exception:
+        limiter = None
     t0 = time.time()
     oracle.train_step(params, state, x, y)
     dt = time.time() - t0
-    return dict(value=round(batch / dt, 4), unit="clips/s", cores=os.cpu_count(), kind="port",
+    if limiter is not None:
+        limiter.restore_original_limits()
+    return dict(value=round(batch / dt, 4), unit="clips/s", cores=cores, kind="port",
                 sample="one train step (fwd+loss+bwd+Adam) of %d clip(s) 16x112x112, numpy/OpenBLAS oracle, %.1f s" % (batch, dt))
 
 
