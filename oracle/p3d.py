@@ -368,12 +368,13 @@ def forward(params, x, dropout=0.0, training=False, structure='unet', cfg=None, 
     return pred.data, g
 
 
-def loss_and_grads(params, x, y, dropout=0.0, training=True, structure='unet', cfg=None, dtype=np.float32):
+def loss_and_grads(params, x, y, dropout=0.0, training=True, structure='unet', cfg=None, dtype=np.float32,
+                   keep_mask=None):
     """Forward + Smooth-L1-sum loss (train.py:156-159) + backward.  Returns
-    (loss, pred, grads{name->array}, graph)."""
+    (loss, pred, grads{name->array}, graph).  keep_mask: the dropout keep pattern when dropout > 0."""
     g = Graph(params, dtype=dtype, create=False)
     X = nn.Var(x.astype(dtype))
-    pred = STRUCTURES[structure](g, X, dropout, x.shape[0], training, cfg)
+    pred = STRUCTURES[structure](g, X, dropout, x.shape[0], training, cfg, keep_mask)
     pred_reshape = nn.reshape(g.tape, pred, y.shape)
     loss = nn.smooth_l1_loss(g.tape, pred_reshape, y.astype(dtype), 1, 1, sigma=1.0)
     g.tape.backward(loss)

@@ -219,3 +219,54 @@ def test_gn_cbam_forward_backward(cfg, shape):
         slack = 1e-2 if n.startswith('cbam_') else 2e-3
         assert rel_l2(s.get_grad(n), w, floor) <= 5 * rel_l2(g32[n], w, floor) + slack, n
     s.close()
+
+
+def test_dropout_forward_backward_parity():
+    """tf.layers.dropout on deconv3_re (p3d.py:214) with rate 0.5: TF's RNG stream cannot be matched, so the keep
+    pattern the HIP path drew is read back and handed to the oracle; loss and every gradient must then agree."""
+    cfg, shape = SMALL[0]
+    p64 = randomise_norm_params(p3d.init_params(1, 'unet', cfg, dtype=np.float64))
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    x = p3d.synthetic_clip(0, shape + (3,))
+    y = p3d.synthetic_target(3, shape)
+    s = make_session(cfg, shape, p32)
+    s.forward(x, 0.0, True)
+    base = s.activation('deconv3_re')
+    loss, pred = s.backward(x, y, dropout=0.5, seed=11)
+    dropped = s.activation('deconv3_re')                     # same seed -> same pattern as the backward above
+    keep = np.where(base != 0, dropped != 0, True)
+    assert 0.45 < keep[base != 0].mean() < 0.55
+    l64, pr64, g64, _ = p3d.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.5, True, 'unet', cfg,
+                                           np.float64, keep_mask=keep.astype(np.float64))
+    _, _, g32, _ = p3d.loss_and_grads(dict(p32), x, y, 0.5, True, 'unet', cfg, np.float32, keep_mask=keep.astype(np.float32))
+    assert abs(loss - l64) < 1e-5 * abs(l64)
+    assert np.abs(pred - pr64).max() < 1e-4
+    scale = np.median([np.linalg.norm(g) for g in g64.values()])
+    for n, want in g64.items():
+        floor = 1e-2 * scale
+        assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3, n
+    s.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 32, 32), (3, 16, 64, 48), (1, 32, 32, 64)])
+def test_odd_batches_and_clip_shapes(shape):
+    """batch 1 (the gen_pred.py case: BN statistics over one clip), a batch that is not a power of two,
+    non-square clips and 32 frames."""
+    cfg = p3d.NetConfig(base=8, blocks=(2, 2, 2))
+    p64 = randomise_norm_params(p3d.init_params(1, 'unet', cfg, dtype=np.float64))
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    x = p3d.synthetic_clip(0, shape + (3,))
+    y = p3d.synthetic_target(3, shape)
+    s = make_session(cfg, shape, p32)
+    want, _ = p3d.forward(p64, x.astype(np.float64), 0.0, False, 'unet', cfg, np.float64)
+    got = s.forward(x, 0.0, False)
+    assert np.abs(got - want).max() / np.abs(want).max() < 2e-4
+    l64, _, g64, _ = p3d.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True, 'unet', cfg, np.float64)
+    _, _, g32, _ = p3d.loss_and_grads(dict(p32), x, y, 0.0, True, 'unet', cfg, np.float32)
+    loss, _ = s.backward(x, y, 0.0)
+    assert abs(loss - l64) < 1e-5 * abs(l64)
+    scale = np.median([np.linalg.norm(g) for g in g64.values()])
+    for n, w in g64.items():
+        floor = 1e-2 * scale
+        assert rel_l2(s.get_grad(n), w, floor) <= 5 * rel_l2(g32[n], w, floor) + 3e-3, n
+    s.close()
