@@ -176,6 +176,9 @@ __device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, co
                 b[j] = make_float4(bp[0], bp[BN], bp[2 * BN], bp[3 * BN]);
             }
         }
+#ifdef P3D_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -187,6 +190,9 @@ __device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, co
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                 }
             }
+#ifdef P3D_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
 }
 
