@@ -137,15 +137,15 @@ def main():
                          (args.gpus, world, args.gpus))
 
     from sap3d_tensorflow_amd import P3DSession
-    from oracle import p3d as oracle          # synthetic-input law only (dataflow.py:204-208)
+    from sap3d_tensorflow_amd import synthetic
 
     B = args.batch
     T, S = args.frames, args.size
     sess = P3DSession(args.structure, batch=B, frames=T, height=S, width=S, device=local_rank, world_size=world, rank=rank, seed=1)
     if world > 1:
         sess.comm_init(plane.share_from_rank0(P3DSession.comm_unique_id))
-    x = oracle.synthetic_clip(rank, (B, T, S, S, 3))
-    y = oracle.synthetic_target(3 + rank, (B, T, S, S))
+    x = synthetic.synthetic_clip(rank, (B, T, S, S, 3))
+    y = synthetic.synthetic_target(3 + rank, (B, T, S, S))
     sess.upload(x, y)
 
     for i in range(args.warmup):

@@ -37,7 +37,7 @@ def get_arguments():
 
 
 def batches(args, rng):
-    from oracle import p3d as law      # only the synthetic-input law (dataflow.py:204-208)
+    from sap3d_tensorflow_amd import synthetic as law
     if args.data:
         d = np.load(args.data)
         x, y = d["x"].astype(np.float32), d["y"].astype(np.float32)

@@ -519,7 +519,7 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split) {
         g_plans[key] = pl;
     }
     const int steps = a.ntaps * ((a.K + BK - 1) / BK);
-    if (const char* e = getenv("P3D_SPLITS")) {            // tuning override (scratch/tune_igemm.py)
+    if (const char* e = getenv("P3D_SPLITS")) {            // tuning override (tools/tune_igemm.py)
         const int v = atoi(e);
         if (v >= 1 && allow_split && v <= steps) pl.splits = v;
     }

@@ -48,7 +48,7 @@ struct IgemmArgs {
     int stem_wstep;       // floats advanced per output column (sw*Cin)
     int stem_wpad;        // floats of left padding (pad_w*Cin)
     const float* zeros;   // >= 128 B of zeros in device memory (source for padded / tail lanes; igemm2 only)
-    int exp;              // tuning experiments only (scratch/tune_igemm.py): 1 skip main loop, 2 skip epilogue
+    int exp;              // tuning experiments only (tools/tune_igemm.py): 1 skip main loop, 2 skip epilogue
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
 };

@@ -69,3 +69,27 @@ def test_gen_pred_driver_host_logic():
     tag = np.arange(20, dtype=np.float32)[:, None, None, None] * np.ones((1, 112, 112, 3), np.float32)
     out = gp.predict_video(Fake(), tag, batch=3)
     assert np.allclose(out[:, 0, 0], np.arange(20))        # frame i's map comes from a window that contains frame i last (or window 0)
+
+
+def test_product_synthetic_inputs_match_the_oracle_law():
+    from oracle import p3d
+    from sap3d_tensorflow_amd import synthetic
+    assert np.array_equal(synthetic.synthetic_clip(3, (1, 16, 8, 8, 3)), p3d.synthetic_clip(3, (1, 16, 8, 8, 3)))
+    assert np.array_equal(synthetic.synthetic_target(4, (1, 16, 8, 8)), p3d.synthetic_target(4, (1, 16, 8, 8)))
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under sap3d_tensorflow_amd/ or drivers/ may import it; bench.py may
+    only inside cpu_baseline()."""
+    import ast
+    for d in ("sap3d_tensorflow_amd", "drivers"):
+        for f in os.listdir(os.path.join(ROOT, d)):
+            if f.endswith(".py"):
+                src = open(os.path.join(ROOT, d, f)).read()
+                assert "oracle" not in [n.split(".")[0] for node in ast.walk(ast.parse(src))
+                                        for n in ([a.name for a in node.names] if isinstance(node, ast.Import) else
+                                                  [node.module or ""] if isinstance(node, ast.ImportFrom) else [])], (d, f)
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+        assert (not uses) or fn.name == "cpu_baseline", fn.name

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for T in 0 1; do for S in 1 2 3 4 6 8 12 16; do
   export P3D_SPLITS=$S P3D_TILE=$T
-  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tune/t${T}_s${S} -- python3 scratch/tune_igemm.py > /dev/null 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tune/t${T}_s${S} -- python3 tools/tune_igemm.py > /dev/null 2>&1
   f=$(ls gpurun_out/tune/t${T}_s${S}/*/*kernel_trace.csv | head -1)
   python3 - "$f" $T $S <<'PY'
 import csv, sys

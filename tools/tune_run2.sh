@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for E in 0 1 2; do for S in 1 6; do
   export P3D_SPLITS=$S P3D_TILE=0 P3D_EXP=$E
-  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tune2/e${E}_s${S} -- python3 scratch/tune_igemm.py > /dev/null 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tune2/e${E}_s${S} -- python3 tools/tune_igemm.py > /dev/null 2>&1
   f=$(ls gpurun_out/tune2/e${E}_s${S}/*/*kernel_trace.csv | head -1)
   python3 - "$f" $E $S <<'PY'
 import csv, sys
