@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 def get_arguments():
     p = argparse.ArgumentParser(description="P3D saliency trainer (MI355X-native)")
     p.add_argument("--normalization", type=str, default="bn", help="bn -> p3d.py graphs, gn -> gn/p3d_gn.py inference_p3d")
-    p.add_argument("--structure", type=str, default="unet", help="unet | concat (train.py:149-154)")
+    p.add_argument("--structure", type=str, default="unet", help="unet | concat | unet++nonsa (train.py:149-154; unet++ without its attention blocks, p3d.py:401)")
     p.add_argument("--batch", type=int, default=2)
     p.add_argument("--lr", type=float, default=1e-4)
     p.add_argument("--epoch", type=int, default=1)

@@ -25,8 +25,11 @@ typedef struct p3d_handle p3d_handle;
 enum {
     P3D_STRUCTURE_UNET = 0,      /* train.py:149-150  --structure unet   -> p3d.p3d_unet   (p3d.py:169) */
     P3D_STRUCTURE_CONCAT = 1,    /* train.py:151-152  --structure concat -> p3d.p3d_concat (p3d.py:224), no sigmoid */
-    P3D_STRUCTURE_GN_P3D = 2     /* gn/train_p3d_gn_dataset.py:169-170 net='P3D' -> p3d_gn.inference_p3d (gn/p3d_gn.py:214):
+    P3D_STRUCTURE_GN_P3D = 2,    /* gn/train_p3d_gn_dataset.py:169-170 net='P3D' -> p3d_gn.inference_p3d (gn/p3d_gn.py:214):
                                     GroupNorm + CBAM on every residual, concat head, no sigmoid */
+    P3D_STRUCTURE_UNETPP_NONSA = 3 /* p3d.p3d_unetplusplus_nonsa (p3d.py:401): the nested UNet++ head of
+                                    train.py:153-154 `--structure unet++` with its attention blocks left out
+                                    (layer wrappers utils/network.py:97-110) */
 };
 
 typedef struct p3d_config {

@@ -342,7 +342,53 @@ def p3d_concat(g, _X, _dropout, batch_size=2, training=True, cfg=None, keep_mask
     return results
 
 
-STRUCTURES = {'unet': p3d_unet, 'concat': p3d_concat}     # train.py:149-154
+def p3d_unetplusplus_nonsa(g, _X, _dropout, batch_size=2, training=True, cfg=None, keep_mask=None):
+    """p3d.py:401-459: the nested (UNet++) head without the attention blocks.
+    Layer wrappers are utils/network.py:97-110: tf.layers.conv3d / conv3d_transpose
+    (named), an UNNAMED tf.layers.batch_normalization that follows `training`
+    (so it continues the backbone's batch_normalization_<n> counter in call
+    order), ReLU.  The x_1_0 temporal pool of the stem output (p3d.py:408) is
+    created before pool1, which changes no variable."""
+    cfg = cfg or REFERENCE_CFG
+    t = g.tape
+    b = cfg.base
+    stem, x_2_0, x_3_0, x_4_0 = _encoder(g, _X, training, cfg)
+    x_1_0 = max_pool3d(g, stem, [1, 2, 1, 1, 1], [1, 2, 1, 1, 1])
+    t.tap('x_1_0', x_1_0)
+
+    def transpose_conv3d(x, channel, kernel, strides, name):      # utils/network.py:106-110
+        y = layers_conv3d_transpose(g, x, channel, kernel, strides, name=name)
+        y = nn.relu(t, batch_normalization(g, y, training))
+        t.tap(name, y)
+        return y
+
+    def conv3d(x, channel, kernel, strides, name):                # utils/network.py:100-104
+        y = layers_conv3d(g, x, channel, kernel, strides, name=name)
+        y = nn.relu(t, batch_normalization(g, y, training))
+        t.tap(name, y)
+        return y
+
+    def concat(xs):                                               # utils/network.py:97-98
+        return nn.concat(t, xs)
+    upx_4_0 = transpose_conv3d(x_4_0, 8 * b, [1, 3, 3], [2, 2, 2], 'upx_4_0')
+    x_3_1 = conv3d(concat([x_3_0, upx_4_0]), 8 * b, [2, 3, 3], [1, 1, 1], 'x_3_1')
+    upx_3_0 = transpose_conv3d(x_3_0, 4 * b, [2, 3, 3], [2, 2, 2], 'upx_3_0')
+    x_2_1 = conv3d(concat([x_2_0, upx_3_0]), 4 * b, [3, 3, 3], [1, 1, 1], 'x_2_1')
+    upx_3_1 = transpose_conv3d(x_3_1, 4 * b, [2, 3, 3], [2, 2, 2], 'upx_3_1')
+    x_2_2 = conv3d(concat([x_2_1, upx_3_1]), 4 * b, [3, 3, 3], [1, 1, 1], 'x_2_2')
+    upx_2_0 = transpose_conv3d(x_2_0, 2 * b, [3, 3, 3], [2, 2, 2], 'upx_2_0')
+    x_1_1 = conv3d(concat([x_1_0, upx_2_0]), 2 * b, [3, 3, 3], [1, 1, 1], 'x_1_1')
+    upx_2_1 = transpose_conv3d(x_2_1, 2 * b, [3, 3, 3], [2, 2, 2], 'upx_2_1')
+    x_1_2 = conv3d(concat([x_1_1, upx_2_1]), 2 * b, [3, 3, 3], [1, 1, 1], 'x_1_2')
+    upx_2_2 = transpose_conv3d(x_2_2, 2 * b, [3, 3, 3], [2, 2, 2], 'upx_2_2')
+    x_1_3 = conv3d(concat([x_1_2, upx_2_2]), 2 * b, [3, 3, 3], [1, 1, 1], 'x_1_3')
+    x_1_3 = nn.dropout(t, x_1_3, _dropout, training, keep_mask)
+    x_0_1 = layers_conv3d_transpose(g, x_1_3, 1, 3, 2, name='x_0_1')
+    return nn.sigmoid(t, x_0_1)
+
+
+STRUCTURES = {'unet': p3d_unet, 'concat': p3d_concat,      # train.py:149-154
+              'unet++nonsa': p3d_unetplusplus_nonsa}       # p3d.py:401 (unet++ minus attention)
 
 
 # ---------------------------------------------------------------------------

@@ -65,6 +65,7 @@ struct Act {
     Act* parent = nullptr;          // channel-slice view of parent's storage
     std::vector<Act*> views;
     char* last_flag = nullptr;      // accumulate-flag of the most recently registered consumer
+    bool whole_consumed = false;    // a consumer of the whole buffer (all views) is registered
     int64_t rows() const { return (int64_t)N * D * H * W; }
 };
 
@@ -224,7 +225,7 @@ struct Op {
     std::string name, kind;
     double flops = 0, bytes = 0;            // forward algorithmic work
     double bflops = 0, bbytes = 0;          // backward algorithmic work
-    int64_t first_param_off = -1;           // lowest flat offset of the params this op owns (-1: none)
+    std::vector<struct Param*> owns;        // trainable variables whose gradients this op's backward produces
     std::function<void(const Ctx&)> fwd, bwd;
 };
 
@@ -495,6 +496,11 @@ struct p3d_handle {
         flags.push_back(0);
         char* f = &flags.back();
         std::vector<Act*> region{a};
+        // A concat buffer's whole-buffer consumer must be its newest one: its input gradient is then the
+        // first write of every slice in backward order, and the slices' own consumers add to it.
+        if (a->parent && a->parent->whole_consumed)
+            throw P3dError("consumer of slice " + a->name + " registered after the consumer of its concat buffer " + a->parent->name);
+        if (!a->views.empty()) a->whole_consumed = true;
         if (a->parent) region.push_back(a->parent);
         for (Act* v : a->views) region.push_back(v);
         for (Act* r : region) {
@@ -535,7 +541,7 @@ struct p3d_handle {
     // ---- graph ops ---------------------------------------------------------------------------
     // tf.nn.conv3d / tf.layers.conv3d: SAME conv, optional bias, optional BN-statistics epilogue.
     Act* conv(const std::string& opname, Act* x, Param* w, Param* bias, const int k[3], const int s[3], int Cout, BN* bn,
-              const std::string& out_name, bool stem = false) {
+              const std::string& out_name, bool stem = false, bool bn_has_dropout = false) {
         const ConvGeo g = make_geo(x->D, x->H, x->W, k, s);
         Act* y = new_act(out_name, x->N, g.O[0], g.O[1], g.O[2], Cout);
         char* xflag = x->g ? consume(x) : nullptr;
@@ -547,12 +553,12 @@ struct p3d_handle {
         op.bytes = 4.0 * (x->rows() * (double)Cin + y->rows() * (double)Cout + (double)ntap * Cin * Cout);
         op.bflops = op.flops * (x->g ? 2 : 1);
         op.bbytes = op.bytes * (x->g ? 2 : 1);
-        op.first_param_off = w->off;
+        op.owns = {w}; if (bias) op.owns.push_back(bias);
         hipEvent_t fork_ev = new_fork_event();
         op.fwd = [=](const Ctx& c) {
             std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
                                                         nullptr, 0, stem)};
-            BN* sbn = bn ? stats_target(bn, y->rows(), Cout) : nullptr;
+            BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
             run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? bn_stats(sbn) : nullptr);
         };
         op.bwd = [=](const Ctx& c) {
@@ -585,7 +591,7 @@ struct p3d_handle {
         op.flops = 2.0 * y->rows() * taps_eff * Cin * Cout;
         op.bytes = 4.0 * (x->rows() * (double)Cin + y->rows() * (double)Cout + (double)k[0] * k[1] * k[2] * Cin * Cout);
         op.bflops = 2 * op.flops; op.bbytes = 2 * op.bytes;
-        op.first_param_off = kern->off;
+        op.owns = {kern}; if (bias) op.owns.push_back(bias);
         hipEvent_t fork_ev = new_fork_event();
         op.fwd = [=](const Ctx& c) {
             auto v = igemm_conv_input_side(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, kern->p, bias ? bias->p : nullptr,
@@ -633,8 +639,8 @@ struct p3d_handle {
         const std::string kn_bapply = "bn_bwd_apply_kernel<" + std::to_string(mode) + ">";
         op.flops = 0; op.bytes = tens * (y2 ? 3 : 2);
         op.bflops = 0; op.bbytes = tens * (y2 ? 7 : 5);
-        op.first_param_off = bn1->gamma->off;
-        if (two && bn2->gamma->off < op.first_param_off) op.first_param_off = bn2->gamma->off;
+        op.owns = {bn1->gamma, bn1->beta};
+        if (two) { op.owns.push_back(bn2->gamma); op.owns.push_back(bn2->beta); }
         const bool small = bn_is_small(M, C, dropout);
         auto small_args = [=](const Ctx& c) {
             BnSmallArgs a;
@@ -790,8 +796,8 @@ struct p3d_handle {
         Op op;
         op.name = opname; op.kind = "gn_apply" + std::to_string(mode);
         op.bytes = tens * (y2 ? 4 : 3); op.bbytes = tens * (y2 ? 7 : 5);
-        op.first_param_off = g1->gamma->off;
-        if (g2 && g2->gamma->off < op.first_param_off) op.first_param_off = g2->gamma->off;
+        op.owns = {g1->gamma, g1->beta};
+        if (g2) { op.owns.push_back(g2->gamma); op.owns.push_back(g2->beta); }
         auto mk = [=](const Ctx& c, bool bwd) {
             GnApplyArgs a;
             memset(&a, 0, sizeof(a));
@@ -886,7 +892,7 @@ struct p3d_handle {
         Op op;
         op.name = "block" + std::to_string(id) + "/cbam"; op.kind = "cbam";
         op.bytes = 4.0 * 2 * x->rows() * C; op.bbytes = 4.0 * 7 * x->rows() * C;
-        op.first_param_off = cb->k0->off;
+        op.owns = {cb->k0, cb->b0, cb->k1, cb->b1, cb->k7};
         op.fwd = [=](const Ctx& c) { launch(c, "cbam_forward(4 kernels)", 0, 8.0 * x->rows() * C, [&]() { return p3d_cbam_forward(cbam_args(cb), c.s); }); };
         op.bwd = [=](const Ctx& c) { launch(c, "cbam_backward(6 kernels)", 0, 28.0 * x->rows() * C, [&]() { return p3d_cbam_backward(cbam_args(cb), c.s); }); };
         ops.push_back(op);
@@ -1052,6 +1058,7 @@ struct p3d_handle {
 
     // p3d.py:170-195: stem + three stages + temporal pools, shared verbatim by every head.  skip[0..1] are
     // where pool2 / pool3 land (channel slices of decoder concat buffers for the unet head, or null).
+    Act* stem_out = nullptr;     // conv1_custom_bn_relu, which the unet++ head pools a second time (p3d.py:408)
     void build_encoder(Act* skip2, Act* skip3, Act*& pool2, Act*& pool3, Act*& pool4) {
         const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
         if (T % 16 || H % 16 || W % 16) throw P3dError("frames/height/width must be multiples of 16");
@@ -1063,6 +1070,7 @@ struct p3d_handle {
         BN* bn0 = add_bn("", b, true);
         Act* c1 = conv("stem/conv", x_in, w0, nullptr, k177, s122, b, bn0, "conv1_custom", /*stem=*/true);
         Act* a1 = bn_apply("stem/bn", 0, c1, bn0, nullptr, nullptr, nullptr, "conv1_custom_bn_relu");
+        stem_out = a1;
         const int k233[3] = {2, 3, 3}, s222[3] = {2, 2, 2}, k211[3] = {2, 1, 1}, s211[3] = {2, 1, 1};
         Act* cur = maxpool("pool1", a1, k233, s222, nullptr, "pool1");
         int id = 0, inpl = b;
@@ -1155,6 +1163,72 @@ struct p3d_handle {
         head(zr, kp, bp, /*with_sigmoid=*/false);
     }
 
+    // p3d_unetplusplus_nonsa (p3d.py:401-459): the nested UNet++ head without the attention blocks.  Every layer
+    // is utils/network.py:100-110: named tf.layers.conv3d / conv3d_transpose + an UNNAMED batch_normalization
+    // (it follows `training` and continues the backbone's counter in the reference's call order) + ReLU.
+    // Variables are therefore created in the reference's order, but the ops run in an order in which each
+    // concat buffer's whole consumer (the x_i_j conv) comes after every consumer of one of its slices -- see
+    // consume().  Concats are zero-copy: producers write channel slices of the buffers below.
+    void build_unetpp_nonsa() {
+        const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
+        const int s111[3] = {1, 1, 1}, s222[3] = {2, 2, 2}, k211[3] = {2, 1, 1}, s211[3] = {2, 1, 1};
+        Act* cat31 = new_act("cat_x_3_1", B, T / 8, H / 8, W / 8, 16 * b);    // [x_3_0 | upx_4_0]
+        Act* cat21 = new_act("cat_x_2_1", B, T / 4, H / 4, W / 4, 8 * b);     // [x_2_0 | upx_3_0]
+        Act* cat22 = new_act("cat_x_2_2", B, T / 4, H / 4, W / 4, 8 * b);     // [x_2_1 | upx_3_1]
+        Act* cat11 = new_act("cat_x_1_1", B, T / 2, H / 2, W / 2, 3 * b);     // [x_1_0 | upx_2_0]
+        Act* cat12 = new_act("cat_x_1_2", B, T / 2, H / 2, W / 2, 4 * b);     // [x_1_1 | upx_2_1]
+        Act* cat13 = new_act("cat_x_1_3", B, T / 2, H / 2, W / 2, 4 * b);     // [x_1_2 | upx_2_2]
+        Act *x_2_0, *x_3_0, *x_4_0;
+        build_encoder(new_view(cat21, 0, 4 * b, "pool2"), new_view(cat31, 0, 8 * b, "pool3"), x_2_0, x_3_0, x_4_0);
+        Act* x_1_0 = maxpool("x_1_0", stem_out, k211, s211, new_view(cat11, 0, b, ""), "x_1_0");
+        (void)x_1_0;
+        struct Layer { Param *k, *bias; BN* bn; int filters; int kk[3]; bool up; };
+        std::map<std::string, Layer> L;
+        auto declare = [&](const char* name, bool up, int cin, int filters, int kd) {
+            Layer l;
+            l.up = up; l.filters = filters; l.kk[0] = kd; l.kk[1] = 3; l.kk[2] = 3;
+            l.k = up ? conv_weight(std::string(name) + "/kernel", {kd, 3, 3, filters, cin})
+                     : conv_weight(std::string(name) + "/kernel", {kd, 3, 3, cin, filters});
+            l.bias = add_param(std::string(name) + "/bias", {filters}, true, INIT_ZEROS);
+            l.bn = add_bn("", filters, true);
+            L[name] = l;
+        };
+        // reference creation order (p3d.py:435-451)
+        declare("upx_4_0", true, 16 * b, 8 * b, 1);
+        declare("x_3_1", false, 16 * b, 8 * b, 2);
+        declare("upx_3_0", true, 8 * b, 4 * b, 2);
+        declare("x_2_1", false, 8 * b, 4 * b, 3);
+        declare("upx_3_1", true, 8 * b, 4 * b, 2);
+        declare("x_2_2", false, 8 * b, 4 * b, 3);
+        declare("upx_2_0", true, 4 * b, 2 * b, 3);
+        declare("x_1_1", false, 3 * b, 2 * b, 3);
+        declare("upx_2_1", true, 4 * b, 2 * b, 3);
+        declare("x_1_2", false, 4 * b, 2 * b, 3);
+        declare("upx_2_2", true, 4 * b, 2 * b, 3);
+        declare("x_1_3", false, 4 * b, 2 * b, 3);
+        auto run = [&](const char* name, Act* x, Act* out, bool dropout = false) -> Act* {
+            const Layer& l = L.at(name);
+            Act* y = l.up ? deconv(name, x, l.k, l.bias, l.kk, s222, l.filters, l.bn, "", dropout)
+                          : conv(name, x, l.k, l.bias, l.kk, s111, l.filters, l.bn, "", false, dropout);
+            return bn_apply(std::string(name) + "_bn", 0, y, l.bn, nullptr, nullptr, out, name, dropout);
+        };
+        run("upx_4_0", x_4_0, new_view(cat31, 8 * b, 8 * b, ""));
+        run("upx_3_0", x_3_0, new_view(cat21, 4 * b, 4 * b, ""));
+        run("upx_2_0", x_2_0, new_view(cat11, b, 2 * b, ""));
+        Act* x_3_1 = run("x_3_1", cat31, nullptr);
+        Act* x_2_1 = run("x_2_1", cat21, new_view(cat22, 0, 4 * b, ""));
+        run("x_1_1", cat11, new_view(cat12, 0, 2 * b, ""));
+        run("upx_3_1", x_3_1, new_view(cat22, 4 * b, 4 * b, ""));
+        run("upx_2_1", x_2_1, new_view(cat12, 2 * b, 2 * b, ""));
+        Act* x_2_2 = run("x_2_2", cat22, nullptr);
+        run("x_1_2", cat12, new_view(cat13, 0, 2 * b, ""));
+        run("upx_2_2", x_2_2, new_view(cat13, 2 * b, 2 * b, ""));
+        Act* x_1_3 = run("x_1_3", cat13, nullptr, /*dropout=*/true);
+        Param* kh = conv_weight("x_0_1/kernel", {3, 3, 3, 1, 2 * b});
+        Param* bh = add_param("x_0_1/bias", {1}, true, INIT_ZEROS);
+        head(x_1_3, kh, bh);
+    }
+
     // results = sigmoid(conv3d_transpose(x, 1, 3, 2)) (p3d.py:217-219) + Smooth-L1 (train.py:156-159)
     bool head_sigmoid = true;
     void head(Act* x, Param* k, Param* bias, bool with_sigmoid = true) {
@@ -1170,7 +1244,7 @@ struct p3d_handle {
         op.flops = 2.0 * x->rows() * 27 * x->C;
         op.bytes = 4.0 * (x->rows() * (double)x->C + 2.0 * pred->rows());
         op.bflops = 2 * op.flops; op.bbytes = 4.0 * (3.0 * x->rows() * (double)x->C + 2.0 * pred->rows());
-        op.first_param_off = k->off;
+        op.owns = {k, bias};
         auto mk = [=]() {
             HeadArgs a;
             memset(&a, 0, sizeof(a));
@@ -1205,8 +1279,33 @@ struct p3d_handle {
         bnbuf = dalloc<float>(bnbuf_count);
         for (auto& f : late_bind) f();
         late_bind.clear();
+        index_gradient_owners();
         tune_plans();
         plan_zero_arenas();
+    }
+
+    // Bucketed all-reduce needs to know, after the backward of op i, the lowest flat offset above which every
+    // gradient is final.  Variables are laid out in TF creation order, which need not be op order (the unet++
+    // head creates its layers in the reference's order but runs them in a concat-safe order), so index the
+    // owners: own_sorted = (offset, op index) ascending by offset, own_sufmin[p] = min op index over [p, end).
+    std::vector<std::pair<int64_t, int>> own_sorted;
+    std::vector<int> own_sufmin;
+    void index_gradient_owners() {
+        std::map<const Param*, int> owner;
+        for (size_t i = 0; i < ops.size(); ++i)
+            for (Param* p : ops[i].owns) {
+                if (!p || !p->trainable) continue;
+                if (owner.count(p)) throw P3dError("variable " + p->name + " has two gradient producers");
+                owner[p] = (int)i;
+            }
+        for (Param* p : porder)
+            if (p->trainable && !owner.count(p)) throw P3dError("variable " + p->name + " has no gradient producer");
+        own_sorted.clear();
+        for (auto& kv : owner) own_sorted.push_back({kv.first->off, kv.second});
+        std::sort(own_sorted.begin(), own_sorted.end());
+        own_sufmin.assign(own_sorted.size(), 0);
+        int m = (int)ops.size();
+        for (size_t p = own_sorted.size(); p-- > 0;) { m = std::min(m, own_sorted[p].second); own_sufmin[p] = m; }
     }
 
     // One forward + backward over garbage data with the kernels' autotuners switched on: every distinct conv
@@ -1293,14 +1392,16 @@ struct p3d_handle {
         HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
         HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), c.s));
         int64_t hi = n_train;                        // grads in [hi, n_train) are already handed to the comm stream
+        size_t own_pos = own_sorted.size();
         for (int i = (int)ops.size() - 1; i >= 0; --i) {
             if (c.prof) c.prof->cur_op = ops[i].name;
             ops[i].bwd(c);
             debug_sync("bwd", ops[i], c);
-            if (allreduce && comm && ops[i].first_param_off >= 0) {
-                // every parameter at offset >= first_param_off of op i is final now (creation order = forward order)
-                const int64_t lo = ops[i].first_param_off;
-                if (hi - lo >= bucket_floats || i == 0) {
+            if (allreduce && comm) {
+                // gradients at flat offsets >= lo belong to ops i.. only, so they are final now
+                while (own_pos > 0 && own_sufmin[own_pos - 1] >= i) --own_pos;
+                const int64_t lo = own_pos < own_sorted.size() ? own_sorted[own_pos].first : n_train;
+                if ((hi > lo && hi - lo >= bucket_floats) || i == 0) {
                     const int64_t start = (i == 0) ? 0 : lo;
                     if (hi > start) reduce_range(start, hi, c);
                     hi = start;
@@ -1407,12 +1508,13 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         HIPCHECK(hipEventCreateWithFlags(&h->ev_side_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_comm_done, hipEventDisableTiming));
-        if (cfg->structure < P3D_STRUCTURE_UNET || cfg->structure > P3D_STRUCTURE_GN_P3D) throw P3dError("unknown structure");
+        if (cfg->structure < P3D_STRUCTURE_UNET || cfg->structure > P3D_STRUCTURE_UNETPP_NONSA) throw P3dError("unknown structure");
         if (cfg->batch < 1) throw P3dError("batch must be >= 1");
         for (int i = 0; i < 3; ++i)
             if (cfg->blocks[i] < 1) throw P3dError("blocks must be >= 1");
         if (cfg->structure == P3D_STRUCTURE_CONCAT) h->build_concat();
         else if (cfg->structure == P3D_STRUCTURE_GN_P3D) h->build_gn_p3d();
+        else if (cfg->structure == P3D_STRUCTURE_UNETPP_NONSA) h->build_unetpp_nonsa();
         else h->build_unet();
         h->finalize_build();
         HIPCHECK(hipStreamSynchronize(h->stream));

@@ -7,7 +7,8 @@ import numpy as np
 from . import _lib
 from ._lib import P3dConfig, P3dError, P3dOpTime, check, fptr, lib
 
-STRUCTURES = {"unet": 0, "concat": 1, "gn_p3d": 2}      # train.py:149-154 --structure
+STRUCTURES = {"unet": 0, "concat": 1, "gn_p3d": 2,     # train.py:149-154 --structure
+              "unet++nonsa": 3}                          # p3d.py:401 p3d_unetplusplus_nonsa
 
 
 class P3DSession:

@@ -30,7 +30,10 @@ def rel_l2(a, b, floor):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), floor)
 
 
-@pytest.mark.parametrize("structure", ["unet", "concat"])
+TORCH_METHOD = {"unet": "unet", "concat": "concat", "unet++nonsa": "unetpp_nonsa"}
+
+
+@pytest.mark.parametrize("structure", ["unet", "concat", "unet++nonsa"])
 @pytest.mark.parametrize("training", [True, False])
 def test_small_net_fp64(structure, training):
     cfg = p3d.NetConfig(base=8, blocks=(3, 3, 3))
@@ -39,7 +42,7 @@ def test_small_net_fp64(structure, training):
     y = p3d.synthetic_target(3, (2, 16, 32, 32)).astype(np.float64)
     loss, pred, grads, g = p3d.loss_and_grads(params, x, y, 0.0, training, structure, cfg, np.float64)
     m = torch_ref.TorchP3D(params, torch.float64, cfg.base, cfg.blocks)
-    tp = getattr(m, structure)(torch.tensor(x), training)
+    tp = getattr(m, TORCH_METHOD[structure])(torch.tensor(x), training)
     tl = torch_ref.smooth_l1_sum(tp.reshape(y.shape), torch.tensor(y))
     tl.backward()
     assert abs(loss - tl.item()) <= 1e-10 * abs(tl.item())

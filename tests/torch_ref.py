@@ -117,6 +117,7 @@ class TorchP3D:
     def encoder(self, x, training):
         p, b = self.p, self.base
         x = torch.relu(self.bn(conv3d_same(x, p['firstconv1'], (1, 2, 2)), training))
+        self.stem = x
         x = max_pool_same(x, (2, 3, 3), (2, 2, 2))
         i = 0
         skips = []
@@ -162,6 +163,39 @@ class TorchP3D:
         c = up(c, 'deconv_revise', (2, 2, 2), 'deconv1_revise_bn')
         c = conv3d_transpose_same(c, p['predict_revise/kernel'], (2, 2, 2), p['predict_revise/bias'])
         return c.permute(0, 2, 3, 4, 1)
+
+
+def _unetpp_nonsa(self, x_ndhwc, training):
+    """p3d.py:401-459 with utils/network.py:97-110 wrappers (unnamed BN follows `training`)."""
+    p = self.p
+    x = x_ndhwc.permute(0, 4, 1, 2, 3)
+    x_2_0, x_3_0, x_4_0 = self.encoder(x, training)
+    x_1_0 = max_pool_same(self.stem, (2, 1, 1), (2, 1, 1))
+
+    def up(t, name, s=(2, 2, 2)):
+        y = conv3d_transpose_same(t, p[name + '/kernel'], s, p[name + '/bias'])
+        return torch.relu(self.bn(y, training))
+
+    def conv(ts, name):
+        y = conv3d_same(torch.cat(ts, 1), p[name + '/kernel'], (1, 1, 1), p[name + '/bias'])
+        return torch.relu(self.bn(y, training))
+    upx_4_0 = up(x_4_0, 'upx_4_0')
+    x_3_1 = conv([x_3_0, upx_4_0], 'x_3_1')
+    upx_3_0 = up(x_3_0, 'upx_3_0')
+    x_2_1 = conv([x_2_0, upx_3_0], 'x_2_1')
+    upx_3_1 = up(x_3_1, 'upx_3_1')
+    x_2_2 = conv([x_2_1, upx_3_1], 'x_2_2')
+    upx_2_0 = up(x_2_0, 'upx_2_0')
+    x_1_1 = conv([x_1_0, upx_2_0], 'x_1_1')
+    upx_2_1 = up(x_2_1, 'upx_2_1')
+    x_1_2 = conv([x_1_1, upx_2_1], 'x_1_2')
+    upx_2_2 = up(x_2_2, 'upx_2_2')
+    x_1_3 = conv([x_1_2, upx_2_2], 'x_1_3')
+    d = conv3d_transpose_same(x_1_3, p['x_0_1/kernel'], (2, 2, 2), p['x_0_1/bias'])
+    return torch.sigmoid(d).permute(0, 2, 3, 4, 1)
+
+
+TorchP3D.unetpp_nonsa = _unetpp_nonsa
 
 
 def smooth_l1_sum(pred, y):
