@@ -27,9 +27,13 @@ enum {
     P3D_STRUCTURE_CONCAT = 1,    /* train.py:151-152  --structure concat -> p3d.p3d_concat (p3d.py:224), no sigmoid */
     P3D_STRUCTURE_GN_P3D = 2,    /* gn/train_p3d_gn_dataset.py:169-170 net='P3D' -> p3d_gn.inference_p3d (gn/p3d_gn.py:214):
                                     GroupNorm + CBAM on every residual, concat head, no sigmoid */
-    P3D_STRUCTURE_UNETPP_NONSA = 3 /* p3d.p3d_unetplusplus_nonsa (p3d.py:401): the nested UNet++ head of
+    P3D_STRUCTURE_UNETPP_NONSA = 3, /* p3d.p3d_unetplusplus_nonsa (p3d.py:401): the nested UNet++ head of
                                     train.py:153-154 `--structure unet++` with its attention blocks left out
                                     (layer wrappers utils/network.py:97-110) */
+    P3D_STRUCTURE_GN_P3D_DECODER = 4 /* gn/train_p3d_gn_dataset.py:177-178 net='P3D_DECODER' ->
+                                    p3d_gn.inference_p3d_decoder_block (gn/p3d_gn.py:489): GN/CBAM encoder, skip
+                                    deconvs + concat, two conv-deconv-conv decoder blocks, 3x3x3 conv to 1 channel;
+                                    variables live in scope "P3D/"; base must be a multiple of 16 */
 };
 
 typedef struct p3d_config {

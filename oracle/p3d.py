@@ -44,6 +44,7 @@ class Graph:
         self.create = create
         self.tape = nn.Tape()
         self._uniq = {}
+        self.prefix = ''                   # enclosing tf.variable_scope, e.g. 'P3D/' (gn/p3d_gn.py:490)
 
     # -- TF-style unique auto names: batch_normalization, batch_normalization_1, ...
     def unique(self, base):
@@ -52,6 +53,7 @@ class Graph:
         return base if k == 0 else "%s_%d" % (base, k)
 
     def _array(self, name, shape, init):
+        name = self.prefix + name
         if name not in self.params:
             if not self.create:
                 raise KeyError("missing parameter " + name)
@@ -61,10 +63,11 @@ class Graph:
         return a
 
     def variable(self, name, shape, init):
-        if name in self.trainable:
-            return self.trainable[name]
-        v = nn.Var(self._array(name, shape, init), name)
-        self.trainable[name] = v
+        full = self.prefix + name
+        if full in self.trainable:
+            return self.trainable[full]
+        v = nn.Var(self._array(name, shape, init), full)
+        self.trainable[full] = v
         return v
 
     def state(self, name, shape, value):

@@ -185,23 +185,81 @@ def inference_p3d(g, _X, _dropout, batch_size=2, training=True, cfg=None, keep_m
     return results
 
 
-def init_params(seed=1, cfg=None, input_shape=(1, 16, 32, 32, 3), dtype=np.float32):
+def conv3d_layers(g, x, filters, kernel, strides, name):
+    """gn/p3d_gn.py:14-17 (xavier_initializer() = glorot uniform, the tf.layers default)."""
+    return GNReLU(g, layers_conv3d(g, x, filters, kernel, strides, name=name))
+
+
+def deconv3d_layers(g, x, filters, kernel, strides, name):
+    """gn/p3d_gn.py:19-22."""
+    return GNReLU(g, layers_conv3d_transpose(g, x, filters, kernel, strides, name=name))
+
+
+def inference_p3d_decoder_block(g, _X, _dropout, batch_size=2, training=True, cfg=None, keep_mask=None):
+    """gn/p3d_gn.py:489-539 (net='P3D_DECODER', gn/train_p3d_gn_dataset.py:177).  The whole graph is built
+    inside tf.variable_scope('P3D'), so every variable name carries the 'P3D/' prefix."""
+    cfg = cfg or REFERENCE_CFG
+    t = g.tape
+    b = cfg.base
+    g.prefix = 'P3D/'
+    cnt = 0
+    conv1_custom = nn.conv3d(t, _X, get_conv_weight(g, 'firstconv1', [1, 7, 7, 3, b]), (1, 2, 2))
+    conv1_custom_bn_relu = nn.relu(t, GroupNorm(g, conv1_custom))
+    pool1 = max_pool3d(g, conv1_custom_bn_relu, [1, 2, 3, 3, 1], [1, 2, 2, 2, 1])
+    b1 = make_block(g, pool1, b, cfg.blocks[0], b, cnt, depth_3d=cfg.depth_3d)
+    res1 = b1.infer()
+    cnt = b1.cnt
+    pool2 = max_pool3d(g, res1, [1, 2, 1, 1, 1], [1, 2, 1, 1, 1])
+    deconv_pool2 = deconv3d_layers(g, pool2, 2 * b, [3, 3, 3], [1, 1, 1], 'deconv_pool2')
+    t.tap('deconv_pool2', deconv_pool2)
+    b2 = make_block(g, pool2, 2 * b, cfg.blocks[1], 4 * b, cnt, depth_3d=cfg.depth_3d, stride=2)
+    res2 = b2.infer()
+    cnt = b2.cnt
+    pool3 = max_pool3d(g, res2, [1, 2, 1, 1, 1], [1, 2, 1, 1, 1])
+    deconv_pool3 = deconv3d_layers(g, pool3, 4 * b, [2, 3, 3], [2, 2, 2], 'deconv_pool3')
+    t.tap('deconv_pool3', deconv_pool3)
+    b3 = make_block(g, pool3, 4 * b, cfg.blocks[2], 8 * b, cnt, depth_3d=cfg.depth_3d, stride=2)
+    res3 = b3.infer()
+    pool4 = max_pool3d(g, res3, [1, 2, 1, 1, 1], [1, 2, 1, 1, 1])
+    deconv_pool4 = deconv3d_layers(g, pool4, 8 * b, [1, 3, 3], [4, 4, 4], 'deconv_pool4')
+    t.tap('deconv_pool4', deconv_pool4)
+    concatenator = nn.concat(t, [deconv_pool2, deconv_pool3, deconv_pool4])
+    x = conv3d_layers(g, concatenator, 16 * b, 3, 1, 'conv_concat')
+    t.tap('conv_concat', x)
+    for name, fn, filters, stride in (('decoder1_conv1', conv3d_layers, 4 * b, 1),
+                                      ('decoder1_deconv', deconv3d_layers, 4 * b, 2),
+                                      ('decoder1_conv2', conv3d_layers, 2 * b, 1),
+                                      ('decoder2_conv1', conv3d_layers, b // 2, 1),
+                                      ('decoder2_deconv', deconv3d_layers, b // 2, 2),
+                                      ('decoder2_conv2', conv3d_layers, b // 4, 1)):
+        x = fn(g, x, filters, 3, stride, name)
+        t.tap(name, x)
+    final_conv = nn.dropout(t, x, _dropout, training, keep_mask)
+    results = layers_conv3d(g, final_conv, 1, 3, 1, name='results')
+    return results
+
+
+HEADS = {'p3d': inference_p3d,                         # gn/train_p3d_gn_dataset.py:169-170  net='P3D'
+         'decoder': inference_p3d_decoder_block}       # gn/train_p3d_gn_dataset.py:177-178  net='P3D_DECODER'
+
+
+def init_params(seed=1, cfg=None, input_shape=(1, 16, 32, 32, 3), dtype=np.float32, head='p3d'):
     g = Graph(rng=np.random.default_rng(seed), dtype=dtype, create=True)
-    inference_p3d(g, nn.Var(np.zeros(input_shape, dtype)), 0.0, input_shape[0], False, cfg)
+    HEADS[head](g, nn.Var(np.zeros(input_shape, dtype)), 0.0, input_shape[0], False, cfg)
     return g.params
 
 
-def forward(params, x, dropout=0.0, training=False, cfg=None, dtype=np.float32):
+def forward(params, x, dropout=0.0, training=False, cfg=None, dtype=np.float32, head='p3d'):
     g = Graph(params, dtype=dtype, create=False)
-    pred = inference_p3d(g, nn.Var(x.astype(dtype)), dropout, x.shape[0], training, cfg)
+    pred = HEADS[head](g, nn.Var(x.astype(dtype)), dropout, x.shape[0], training, cfg)
     return pred.data, g
 
 
-def loss_and_grads(params, x, y, dropout=0.0, training=True, cfg=None, dtype=np.float32):
+def loss_and_grads(params, x, y, dropout=0.0, training=True, cfg=None, dtype=np.float32, head='p3d', keep_mask=None):
     """gn/train_p3d_gn_dataset.py:186: the same Smooth-L1 sum on the raw prediction."""
     from collections import OrderedDict
     g = Graph(params, dtype=dtype, create=False)
-    pred = inference_p3d(g, nn.Var(x.astype(dtype)), dropout, x.shape[0], training, cfg)
+    pred = HEADS[head](g, nn.Var(x.astype(dtype)), dropout, x.shape[0], training, cfg, keep_mask)
     loss = nn.smooth_l1_loss(g.tape, nn.reshape(g.tape, pred, y.shape), y.astype(dtype), 1, 1, sigma=1.0)
     g.tape.backward(loss)
     return float(loss.data), pred.data, OrderedDict((n, v.grad) for n, v in g.trainable.items()), g

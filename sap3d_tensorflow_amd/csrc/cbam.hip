@@ -12,7 +12,7 @@ namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
 
 // (sum, max, ties) merge
 __device__ __forceinline__ void merge(float& s, float& m, float& t, float s2, float m2, float t2) {
@@ -38,11 +38,14 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(CbamArgs a) {
     }
 }
 
-// block per sample: fold the chunk partials, run the shared MLP on avg and max, cs = sigmoid(sum)
-__global__ __launch_bounds__(256) void chan_mlp_kernel(CbamArgs a) {
-    extern __shared__ float sm[];                  // avg[C] max[C] havg[Ch] hmax[Ch]
-    float* avg = sm; float* mx = sm + a.C; float* ha = mx + a.C; float* hm = ha + a.Ch;
-    const int R = a.D * a.H * a.W, n = blockIdx.x;
+// Shared MLP, hidden layer.  grid (ceil(Ch/8), N): every block folds the sample's chunk partials into avg / max
+// (block x == 0 publishes them), then computes 8 hidden units: thread = (unit u, one of 32 interleaved slices of
+// the C inputs), slices folded through LDS.  The old one-block-per-sample version walked 512 dependent loads per
+// thread and cost 180 us per site.
+__global__ __launch_bounds__(256) void chan_hidden_kernel(CbamArgs a) {
+    extern __shared__ float sm[];                  // avg[C] max[C] part[32][8][2]
+    float* avg = sm; float* mx = sm + a.C; float* part = mx + a.C;
+    const int R = a.D * a.H * a.W, n = blockIdx.y, j0 = blockIdx.x * 8;
     for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
         float s = 0.f, m = -INFINITY, t = 0.f;
         for (int ch = 0; ch < a.chunks; ++ch) {
@@ -50,32 +53,37 @@ __global__ __launch_bounds__(256) void chan_mlp_kernel(CbamArgs a) {
             merge(s, m, t, o[0], o[1], o[2]);
         }
         avg[c] = s / (float)R; mx[c] = m;
-        a.avg[(long long)n * a.C + c] = avg[c]; a.mx[(long long)n * a.C + c] = m; a.ties[(long long)n * a.C + c] = t;
+        if (blockIdx.x == 0) { a.avg[(long long)n * a.C + c] = avg[c]; a.mx[(long long)n * a.C + c] = m; a.ties[(long long)n * a.C + c] = t; }
     }
     __syncthreads();
-    {   // hidden layer: thread = (unit j, slice of the C inputs); slices folded through LDS
-        float* part = hm + a.Ch;                        // [parts][Ch][2]
-        const int parts = blockDim.x / a.Ch > 0 ? blockDim.x / a.Ch : 1;
-        const int j = threadIdx.x % a.Ch, pt = threadIdx.x / a.Ch;
-        if (pt < parts) {
-            const int per = (a.C + parts - 1) / parts;
-            const int c0 = pt * per, c1 = min(a.C, c0 + per);
-            float sa = 0.f, sb = 0.f;
-            for (int c = c0; c < c1; ++c) { const float w = a.k0[c * a.Ch + j]; sa += avg[c] * w; sb += mx[c] * w; }
-            part[(pt * a.Ch + j) * 2] = sa; part[(pt * a.Ch + j) * 2 + 1] = sb;
-        }
-        __syncthreads();
-        if (threadIdx.x < a.Ch) {
-            float sa = a.b0[j], sb = a.b0[j];
-            for (int q = 0; q < parts; ++q) { sa += part[(q * a.Ch + j) * 2]; sb += part[(q * a.Ch + j) * 2 + 1]; }
-            ha[j] = fmaxf(sa, 0.f); hm[j] = fmaxf(sb, 0.f);
-            a.havg[(long long)n * a.Ch + j] = ha[j]; a.hmx[(long long)n * a.Ch + j] = hm[j];
-        }
+    {
+        const int u = threadIdx.x & 7, sl = threadIdx.x >> 3, j = j0 + u;
+        float sa = 0.f, sb = 0.f;
+        if (j < a.Ch)
+            for (int c = sl; c < a.C; c += 32) { const float w = a.k0[(long long)c * a.Ch + j]; sa += avg[c] * w; sb += mx[c] * w; }
+        part[(sl * 8 + u) * 2] = sa; part[(sl * 8 + u) * 2 + 1] = sb;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    if (threadIdx.x < 16) {
+        const int u = threadIdx.x & 7, br = threadIdx.x >> 3, j = j0 + u;
+        if (j < a.Ch) {
+            float s = a.b0[j];
+            for (int q = 0; q < 32; ++q) s += part[(q * 8 + u) * 2 + br];
+            (br ? a.hmx : a.havg)[(long long)n * a.Ch + j] = fmaxf(s, 0.f);
+        }
+    }
+}
+
+// Output layer + sigmoid.  grid (ceil(C/256), N), thread = channel; k1 rows are read coalesced over c.
+__global__ __launch_bounds__(256) void chan_out_kernel(CbamArgs a) {
+    extern __shared__ float h[];                   // [Ch] = havg + hmax (the MLP is shared, so its outputs add)
+    const int n = blockIdx.y;
+    for (int j = threadIdx.x; j < a.Ch; j += blockDim.x) h[j] = a.havg[(long long)n * a.Ch + j] + a.hmx[(long long)n * a.Ch + j];
+    __syncthreads();
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.C) {
         float o = 2.f * a.b1[c];
-        for (int j = 0; j < a.Ch; ++j) o += (ha[j] + hm[j]) * a.k1[j * a.C + c];
+        for (int j = 0; j < a.Ch; ++j) o += h[j] * a.k1[(long long)j * a.C + c];
         a.cs[(long long)n * a.C + c] = sigm(o);
     }
 }
@@ -273,22 +281,27 @@ __global__ __launch_bounds__(256) void bwd_df_kernel(CbamArgs a) {
         a.dcs_part[((long long)n * a.chunks + ch) * a.C + c] = red[c] + red[a.C + c] + red[2 * a.C + c] + red[3 * a.C + c];
 }
 
-// MLP backward, step 1 -- block per sample: dO[n,c] = dcs*cs*(1-cs) (kept in davg as scratch), then the hidden
-// gradients dh_avg / dh_max into dh [n][2][Ch].
+// MLP backward, step 1.  grid (ceil(Ch/8), N): every block folds dO[n,c] = dcs*cs*(1-cs) into LDS (block x == 0
+// publishes it in a.dO), then 8 hidden units per block: 32 lanes per unit walk the k1 row coalesced and fold by
+// shuffles.  dh [n][2][Ch] = gradients of the hidden activations of the avg / max branch.
 __global__ __launch_bounds__(256) void bwd_mlp1_kernel(CbamArgs a) {
     extern __shared__ float dO[];                  // [C]
-    const int n = blockIdx.x;
+    const int n = blockIdx.y, j0 = blockIdx.x * 8;
     for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
         float s = 0.f;
         for (int ch = 0; ch < a.chunks; ++ch) s += a.dcs_part[((long long)n * a.chunks + ch) * a.C + c];
         const float cs = a.cs[(long long)n * a.C + c];
         dO[c] = s * cs * (1.f - cs);
-        a.dcs_part[(long long)n * a.chunks * a.C + c] = dO[c];          // chunk 0 slot now holds dO[n,c]
+        if (blockIdx.x == 0) a.dO[(long long)n * a.C + c] = dO[c];
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < a.Ch; j += blockDim.x) {
-        float s = 0.f;
-        for (int c = 0; c < a.C; ++c) s += a.k1[j * a.C + c] * dO[c];
+    const int sl = threadIdx.x & 31, j = j0 + (threadIdx.x >> 5);
+    float s = 0.f;
+    if (j < a.Ch)
+        for (int c = sl; c < a.C; c += 32) s += a.k1[(long long)j * a.C + c] * dO[c];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (sl == 0 && j < a.Ch) {
         const float ha = a.havg[(long long)n * a.Ch + j], hm = a.hmx[(long long)n * a.Ch + j];
         a.dh[(long long)n * 2 * a.Ch + j] = ha > 0.f ? s : 0.f;
         a.dh[(long long)n * 2 * a.Ch + a.Ch + j] = hm > 0.f ? s : 0.f;
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(256) void bwd_mlp2a_kernel(CbamArgs a) {
         a.davg[i] = da; a.dmx[i] = dm;
         if (n == 0) {
             float s = 0.f;
-            for (int m = 0; m < a.N; ++m) s += a.dcs_part[(long long)m * a.chunks * a.C + c];
+            for (int m = 0; m < a.N; ++m) s += a.dO[(long long)m * a.C + c];
             a.db1[c] += 2.f * s;
         }
     }
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(256) void bwd_mlp2b_kernel(CbamArgs a) {
     for (int n = 0; n < a.N; ++n) {
         const float* dh = a.dh + (long long)n * 2 * a.Ch;
         g0 += a.avg[(long long)n * a.C + c] * dh[j] + a.mx[(long long)n * a.C + c] * dh[a.Ch + j];
-        g1 += (a.havg[(long long)n * a.Ch + j] + a.hmx[(long long)n * a.Ch + j]) * a.dcs_part[(long long)n * a.chunks * a.C + c];
+        g1 += (a.havg[(long long)n * a.Ch + j] + a.hmx[(long long)n * a.Ch + j]) * a.dO[(long long)n * a.C + c];
     }
     a.dk0[i] += g0;
     a.dk1[(long long)j * a.C + c] += g1;
@@ -362,7 +375,8 @@ hipError_t p3d_cbam_forward(const CbamArgs& a, hipStream_t s) {
     if ((a.C & 3) || a.C > 1024 || a.Ch < 1 || a.chunks < 1) return hipErrorInvalidValue;
     const long long M = (long long)a.N * a.D * a.H * a.W;
     hipLaunchKernelGGL(chan_pool_kernel, dim3(a.chunks, a.N), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chan_mlp_kernel, dim3(a.N), dim3(256), (2 * a.C + 2 * a.Ch + 2 * 256) * sizeof(float), s, a);
+    hipLaunchKernelGGL(chan_hidden_kernel, dim3((a.Ch + 7) / 8, a.N), dim3(256), (2 * a.C + 512) * sizeof(float), s, a);
+    hipLaunchKernelGGL(chan_out_kernel, dim3((a.C + 255) / 256, a.N), dim3(256), a.Ch * sizeof(float), s, a);
     hipLaunchKernelGGL(spat_pool_kernel, dim3(capped((M + 3) / 4, 8192)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(spat_conv_kernel, dim3(capped((M + 255) / 256, 4096)), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -375,7 +389,7 @@ hipError_t p3d_cbam_backward(const CbamArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(bwd_spat_conv_kernel, dim3(capped((M + 255) / 256, 4096)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bwd_k7_kernel, dim3(capped((M + 63) / 64, 1024)), dim3(384), 0, s, a);
     hipLaunchKernelGGL(bwd_df_kernel, dim3(a.chunks, a.N), dim3(256), 4 * a.C * sizeof(float), s, a);
-    hipLaunchKernelGGL(bwd_mlp1_kernel, dim3(a.N), dim3(256), a.C * sizeof(float), s, a);
+    hipLaunchKernelGGL(bwd_mlp1_kernel, dim3((a.Ch + 7) / 8, a.N), dim3(256), a.C * sizeof(float), s, a);
     hipLaunchKernelGGL(bwd_mlp2a_kernel, dim3((a.N * a.C + 255) / 256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bwd_mlp2b_kernel, dim3((a.C * a.Ch + 255) / 256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bwd_chan_kernel, dim3(capped((M * (a.C >> 2) + 255) / 256, 4096)), dim3(256), 0, s, a);

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                     float v = acc[i][j][e] + bv;
                     float* dst = p.y + ro + col;
                     if (p.accum) v += *dst;
-                    if (p.sigmoid) v = 1.f / (1.f + __expf(-v));
+                    if (p.sigmoid) v = 1.f / (1.f + expf(-v));
                     *dst = v;
                     s1[j] += v;
                     s2[j] += v * v;

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
                 const float v0 = out[(pd * 2 + ph) * 2], v1 = out[(pd * 2 + ph) * 2 + 1];
                 *reinterpret_cast<float2*>(a.logits + o) = make_float2(v0, v1);
                 *reinterpret_cast<float2*>(a.pred + o) =
-                    a.sigmoid ? make_float2(1.f / (1.f + __expf(-v0)), 1.f / (1.f + __expf(-v1))) : make_float2(v0, v1);
+                    a.sigmoid ? make_float2(1.f / (1.f + expf(-v0)), 1.f / (1.f + expf(-v1))) : make_float2(v0, v1);
             }
     }
 }
@@ -155,7 +155,160 @@ __global__ __launch_bounds__(256) void head_bwd_filter_kernel(HeadArgs a) {
     }
 }
 
+// ---- tf.layers.conv3d(x, 1, 3, 1, 'same') head of the GN decoder-block network (gn/p3d_gn.py:537): the same
+// Cout = 1 stencil at stride 1, SAME padding 1 on every side.  logits[o] = bias + sum_k <x[o+k-1,:], K[k,:,0]>.
+__global__ __launch_bounds__(256) void headc_fwd_kernel(HeadArgs a) {
+    extern __shared__ float kw[];     // [27][C]
+    const int C = a.C;
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) kw[i] = a.k[i];
+    __syncthreads();
+    const long long total = (long long)a.N * a.D * a.H * a.W;
+    const float bias = a.bias[0];
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        long long t = g;
+        const int w = (int)(t % a.W); t /= a.W;
+        const int h = (int)(t % a.H); t /= a.H;
+        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+        float out = bias;
+        for (int kd = 0; kd < 3; ++kd) {
+            const int id = d + kd - 1;
+            if (id < 0 || id >= a.D) continue;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = h + kh - 1;
+                if (ih < 0 || ih >= a.H) continue;
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int iw = w + kk - 1;
+                    if (iw < 0 || iw >= a.W) continue;
+                    const float* xr = a.x + ((((long long)n * a.D + id) * a.H + ih) * a.W + iw) * C;
+                    const float* kp = kw + ((kd * 3 + kh) * 3 + kk) * C;
+                    for (int c = 0; c < C; c += 4) {
+                        const float4 xv = ld4(xr + c);
+                        out += xv.x * kp[c] + xv.y * kp[c + 1] + xv.z * kp[c + 2] + xv.w * kp[c + 3];
+                    }
+                }
+            }
+        }
+        a.logits[g] = out;
+        a.pred[g] = a.sigmoid ? 1.f / (1.f + expf(-out)) : out;
+    }
+}
+
+// dx[i,c] = sum_k dlogits[i-k+1] * K[k,c]
+__global__ __launch_bounds__(256) void headc_bwd_input_kernel(HeadArgs a) {
+    extern __shared__ float kw[];
+    const int C = a.C, c4n = C >> 2;
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) kw[i] = a.k[i];
+    __syncthreads();
+    const long long total = (long long)a.N * a.D * a.H * a.W * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i / c4n;
+        const int c = (int)(i - t * c4n) << 2;
+        const long long g = t;
+        const int w = (int)(t % a.W); t /= a.W;
+        const int h = (int)(t % a.H); t /= a.H;
+        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int kd = 0; kd < 3; ++kd) {
+            const int od = d - kd + 1;
+            if (od < 0 || od >= a.D) continue;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int oh = h - kh + 1;
+                if (oh < 0 || oh >= a.H) continue;
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int ow = w - kk + 1;
+                    if (ow < 0 || ow >= a.W) continue;
+                    const float gdl = a.dlogits[(((long long)n * a.D + od) * a.H + oh) * a.W + ow];
+                    const float* kp = kw + ((kd * 3 + kh) * 3 + kk) * C + c;
+                    acc.x += gdl * kp[0]; acc.y += gdl * kp[1]; acc.z += gdl * kp[2]; acc.w += gdl * kp[3];
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(a.dx + g * C + c) = acc;
+    }
+}
+
+// dK[k,c] = sum_i dlogits[i-k+1] * x[i,c]; block = (256/C) position lanes x C channels, 27 accumulators per thread
+__global__ __launch_bounds__(256) void headc_bwd_filter_kernel(HeadArgs a) {
+    __shared__ float red[256];
+    const int C = a.C;
+    const int lanes = 256 / C;
+    const int c = threadIdx.x % C, sub = threadIdx.x / C;
+    const long long total = (long long)a.N * a.D * a.H * a.W;
+    float acc[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = 0.f;
+    float bsum = 0.f;
+    if (sub < lanes) {
+        for (long long g = (long long)blockIdx.x * lanes + sub; g < total; g += (long long)gridDim.x * lanes) {
+            long long t = g;
+            const int w = (int)(t % a.W); t /= a.W;
+            const int h = (int)(t % a.H); t /= a.H;
+            const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+            const float xv = a.x[g * C + c];
+            if (c == 0) bsum += a.dlogits[g];
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const int od = d - kd + 1, oh = h - kh + 1, ow = w - kk + 1;
+                        float gdl = 0.f;
+                        if (od >= 0 && od < a.D && oh >= 0 && oh < a.H && ow >= 0 && ow < a.W)
+                            gdl = a.dlogits[(((long long)n * a.D + od) * a.H + oh) * a.W + ow];
+                        acc[(kd * 3 + kh) * 3 + kk] += gdl * xv;
+                    }
+        }
+    }
+    for (int q = 0; q < 27; ++q) {
+        red[threadIdx.x] = (sub < lanes) ? acc[q] : 0.f;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float s = 0.f;
+            for (int l = 0; l < lanes; ++l) s += red[l * C + threadIdx.x];
+            unsafeAtomicAdd(a.dk + q * C + threadIdx.x, s);
+        }
+        __syncthreads();
+    }
+    red[threadIdx.x] = (sub < lanes && c == 0) ? bsum : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int l = 0; l < lanes; ++l) s += red[l * C];
+        unsafeAtomicAdd(a.dbias, s);
+    }
+}
+
 }  // namespace
+
+hipError_t p3d_headc_fwd(const HeadArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 256) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.D * a.H * a.W;
+    long long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(headc_fwd_kernel, dim3((unsigned)b), dim3(256), 27 * a.C * sizeof(float), s, a);
+    return hipGetLastError();
+}
+
+hipError_t p3d_headc_bwd_input(const HeadArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 256) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.D * a.H * a.W * (a.C >> 2);
+    long long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(headc_bwd_input_kernel, dim3((unsigned)b), dim3(256), 27 * a.C * sizeof(float), s, a);
+    return hipGetLastError();
+}
+
+hipError_t p3d_headc_bwd_filter(const HeadArgs& a, hipStream_t s) {
+    if (a.C > 256 || a.C < 1 || (256 % a.C)) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.D * a.H * a.W;
+    const int lanes = 256 / a.C;
+    long long b = (total + (long long)lanes * 32 - 1) / ((long long)lanes * 32);
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(headc_bwd_filter_kernel, dim3((unsigned)b), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 hipError_t p3d_head_fwd(const HeadArgs& a, hipStream_t s) {
     if ((a.C & 3) || a.C > 256) return hipErrorInvalidValue;

@@ -453,7 +453,9 @@ struct p3d_handle {
         return k == 0 ? base : base + "_" + std::to_string(k);
     }
 
-    Param* add_param(const std::string& name, std::vector<int64_t> shape, bool trainable, int init) {
+    std::string var_prefix;      // enclosing tf.variable_scope ("P3D/" for gn/p3d_gn.py:490), part of every variable name
+    Param* add_param(const std::string& bare_name, std::vector<int64_t> shape, bool trainable, int init) {
+        const std::string name = var_prefix + bare_name;
         if (pindex.count(name)) throw P3dError("duplicate variable " + name);
         params.emplace_back();
         Param* p = &params.back();
@@ -845,7 +847,8 @@ struct p3d_handle {
     int64_t cbam_dpre_off(CbamSite* cb) { return cbam_ss_off(cb) + cb->x->rows(); }                             // dpre [M]
     int64_t cbam_dsp_off(CbamSite* cb) { return cbam_dpre_off(cb) + cb->x->rows(); }                            // dsp [M][2]
     int64_t cbam_dcs_off(CbamSite* cb) { return cbam_dsp_off(cb) + 2 * cb->x->rows(); }                         // dcs_part [N][chunks][C]
-    int64_t cbam_total(CbamSite* cb) { return ((cbam_dcs_off(cb) + (int64_t)cb->x->N * cb->chunks * cb->x->C + 63) / 64) * 64; }
+    int64_t cbam_dO_off(CbamSite* cb) { return cbam_dcs_off(cb) + (int64_t)cb->x->N * cb->chunks * cb->x->C; }   // dO [N][C]
+    int64_t cbam_total(CbamSite* cb) { return ((cbam_dO_off(cb) + (int64_t)cb->x->N * cb->x->C + 63) / 64) * 64; }
 
     CbamArgs cbam_args(CbamSite* cb) {
         CbamArgs a;
@@ -862,6 +865,7 @@ struct p3d_handle {
         a.havg = b + cbam_h_off(cb); a.hmx = a.havg + (int64_t)x->N * a.Ch; a.dh = a.hmx + (int64_t)x->N * a.Ch;
         a.sp = b + cbam_sp_off(cb); a.ss = b + cbam_ss_off(cb); a.dpre = b + cbam_dpre_off(cb); a.dsp = b + cbam_dsp_off(cb);
         a.dcs_part = b + cbam_dcs_off(cb);
+        a.dO = b + cbam_dO_off(cb);
         a.dout = cb->dout;
         a.dx = x->g; a.lddx = x->ld; a.accx = cb->xflag ? *cb->xflag : 0;
         a.dk0 = cb->k0->g; a.db0 = cb->b0->g; a.dk1 = cb->k1->g; a.db1 = cb->b1->g; a.dk7 = cb->k7->g;
@@ -893,7 +897,7 @@ struct p3d_handle {
         op.name = "block" + std::to_string(id) + "/cbam"; op.kind = "cbam";
         op.bytes = 4.0 * 2 * x->rows() * C; op.bbytes = 4.0 * 7 * x->rows() * C;
         op.owns = {cb->k0, cb->b0, cb->k1, cb->b1, cb->k7};
-        op.fwd = [=](const Ctx& c) { launch(c, "cbam_forward(4 kernels)", 0, 8.0 * x->rows() * C, [&]() { return p3d_cbam_forward(cbam_args(cb), c.s); }); };
+        op.fwd = [=](const Ctx& c) { launch(c, "cbam_forward(5 kernels)", 0, 8.0 * x->rows() * C, [&]() { return p3d_cbam_forward(cbam_args(cb), c.s); }); };
         op.bwd = [=](const Ctx& c) { launch(c, "cbam_backward(6 kernels)", 0, 28.0 * x->rows() * C, [&]() { return p3d_cbam_backward(cbam_args(cb), c.s); }); };
         ops.push_back(op);
         return cb;
@@ -940,34 +944,27 @@ struct p3d_handle {
     }
 
     // inference_p3d, gn/p3d_gn.py:214-258
-    void build_gn_p3d() {
+    // Stem + three GN/CBAM stages + temporal pools shared by the heads of gn/p3d_gn.py (:215-240, :491-516).
+    // before_stage(stage, input) runs before the blocks of stages 1 and 2 so that a head can create its skip
+    // transposed convs where the reference does (GroupNorm scopes are numbered in creation order).
+    void build_gn_encoder(Act* skip2, const std::function<void(int, Act*)>& before_stage, Act* pools[3]) {
         const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
         if (T % 16 || H % 16 || W % 16) throw P3dError("frames/height/width must be multiples of 16");
         if (b % 8) throw P3dError("base must be a multiple of 8");
         x_in = new_act("x", B, T, H, W, 3, false);
         const int k177[3] = {1, 7, 7}, s122[3] = {1, 2, 2}, k233[3] = {2, 3, 3}, s222[3] = {2, 2, 2};
-        const int k211[3] = {2, 1, 1}, s211[3] = {2, 1, 1}, k333[3] = {3, 3, 3}, s111[3] = {1, 1, 1}, s444[3] = {4, 4, 4};
+        const int k211[3] = {2, 1, 1}, s211[3] = {2, 1, 1};
         Param* w0 = conv_weight("firstconv1", {1, 7, 7, 3, b});
         GN* g0 = add_gn(b);
         Act* c1 = conv("stem/conv", x_in, w0, nullptr, k177, s122, b, nullptr, "conv1_custom", true);
         Act* a1 = gn_apply("stem/gn", 0, c1, g0, nullptr, nullptr, nullptr, "conv1_custom_bn_relu");
         Act* cur = maxpool("pool1", a1, k233, s222, nullptr, "pool1");
-        // concatenator = [deconv_pool3_gn (8b) | deconv_pool4_gn (16b) | pool2 (4b)]  (gn/p3d_gn.py:251)
-        Act* cat = new_act("concatenator", B, T / 4, H / 4, W / 4, 28 * b);
         int id = 0, inpl = b;
         const int planes[3] = {b, 2 * b, 4 * b};
-        Act* pools[3] = {nullptr, nullptr, nullptr};
-        Act* skips[3] = {new_view(cat, 24 * b, 4 * b, "pool2"), nullptr, nullptr};
+        Act* skips[3] = {skip2, nullptr, nullptr};
         const char* pool_names[3] = {"pool2", "pool3", "pool4"};
-        auto up = [&](const char* name, Act* x, int filters, const int* s, int coff) {
-            Param* k = conv_weight(std::string(name) + "/kernel", {3, 3, 3, filters, x->C});
-            Param* bi = add_param(std::string(name) + "/bias", {filters}, true, INIT_ZEROS);
-            GN* g = add_gn(filters);
-            Act* y = deconv(name, x, k, bi, k333, s, filters, nullptr, "");
-            gn_apply(std::string(name) + "_gn", 0, y, g, nullptr, nullptr, new_view(cat, coff, filters, ""), "");
-        };
         for (int stage = 0; stage < 3; ++stage) {
-            if (stage == 2) up("deconv_pool3", pools[1], 8 * b, s222, 0);      // created before stage 3
+            if (stage > 0 && before_stage) before_stage(stage, cur);
             for (int j = 0; j < cfg.blocks[stage]; ++j) {
                 cur = bottleneck_gn(cur, id, inpl, planes[stage], j == 0, stage > 0);
                 inpl = planes[stage] * 4;
@@ -976,20 +973,63 @@ struct p3d_handle {
             cur = maxpool(pool_names[stage], cur, k211, s211, skips[stage], pool_names[stage]);
             pools[stage] = cur;
         }
-        up("deconv_pool4", pools[2], 16 * b, s444, 8 * b);
-        Param* kc = conv_weight("conv_concat/kernel", {3, 3, 3, 28 * b, 16 * b});
-        Param* bc = add_param("conv_concat/bias", {16 * b}, true, INIT_ZEROS);
-        GN* gc = add_gn(16 * b);
-        Act* yc = conv("conv_concat", cat, kc, bc, k333, s111, 16 * b, nullptr, "");
-        Act* zc = gn_apply("conv_concat_gn", 0, yc, gc, nullptr, nullptr, nullptr, "conv_concat");
-        Param* kr = conv_weight("deconv_revise/kernel", {3, 3, 3, 4 * b, 16 * b});
-        Param* br = add_param("deconv_revise/bias", {4 * b}, true, INIT_ZEROS);
-        GN* gr = add_gn(4 * b);
-        Act* yr = deconv("deconv_revise", zc, kr, br, k333, s222, 4 * b, nullptr, "");
-        Act* zr = gn_apply("deconv_revise_gn", 0, yr, gr, nullptr, nullptr, nullptr, "deconv_revise", /*dropout=*/true);
+    }
+    // tf.layers.conv3d / conv3d_transpose + GNReLU (gn/p3d_gn.py:14-22,49-51), optionally into a concat slice
+    Act* gn_layer(const char* name, bool up, Act* x, int filters, const int* k, const int* s, Act* out,
+                  const std::string& out_name, bool dropout = false) {
+        Param* kern = up ? conv_weight(std::string(name) + "/kernel", {k[0], k[1], k[2], filters, x->C})
+                         : conv_weight(std::string(name) + "/kernel", {k[0], k[1], k[2], x->C, filters});
+        Param* bi = add_param(std::string(name) + "/bias", {filters}, true, INIT_ZEROS);
+        GN* g = add_gn(filters);
+        Act* y = up ? deconv(name, x, kern, bi, k, s, filters, nullptr, "") : conv(name, x, kern, bi, k, s, filters, nullptr, "");
+        return gn_apply(std::string(name) + "_gn", 0, y, g, nullptr, nullptr, out, out_name, dropout);
+    }
+
+    // inference_p3d (gn/p3d_gn.py:214-258)
+    void build_gn_p3d() {
+        const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
+        const int k333[3] = {3, 3, 3}, s111[3] = {1, 1, 1}, s222[3] = {2, 2, 2}, s444[3] = {4, 4, 4};
+        // concatenator = [deconv_pool3_gn (8b) | deconv_pool4_gn (16b) | pool2 (4b)]  (gn/p3d_gn.py:251)
+        Act* cat = new_act("concatenator", B, T / 4, H / 4, W / 4, 28 * b);
+        Act* pools[3] = {nullptr, nullptr, nullptr};
+        build_gn_encoder(new_view(cat, 24 * b, 4 * b, "pool2"), [&](int stage, Act* in) {
+            if (stage == 2) gn_layer("deconv_pool3", true, in, 8 * b, k333, s222, new_view(cat, 0, 8 * b, ""), "");   // before stage 3
+        }, pools);
+        gn_layer("deconv_pool4", true, pools[2], 16 * b, k333, s444, new_view(cat, 8 * b, 16 * b, ""), "");
+        Act* zc = gn_layer("conv_concat", false, cat, 16 * b, k333, s111, nullptr, "conv_concat");
+        Act* zr = gn_layer("deconv_revise", true, zc, 4 * b, k333, s222, nullptr, "deconv_revise", /*dropout=*/true);
         Param* kp = conv_weight("predict_revise/kernel", {3, 3, 3, 1, 4 * b});
         Param* bp = add_param("predict_revise/bias", {1}, true, INIT_ZEROS);
         head(zr, kp, bp, /*with_sigmoid=*/false);
+    }
+
+    // inference_p3d_decoder_block (gn/p3d_gn.py:489-539, net = 'P3D_DECODER' in gn/train_p3d_gn_dataset.py:177):
+    // everything lives in tf.variable_scope('P3D'); skip deconvs of pool2/3/4 to 4x28x28, concat, conv_concat, two
+    // conv-deconv-conv decoder blocks narrowing to base/4 channels at full resolution, dropout, and a plain
+    // 3x3x3 conv to one channel (no sigmoid).
+    void build_gn_decoder() {
+        const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
+        if (b % 16) throw P3dError("the decoder-block head needs base to be a multiple of 16");
+        var_prefix = "P3D/";
+        const int k333[3] = {3, 3, 3}, k233[3] = {2, 3, 3}, k133[3] = {1, 3, 3};
+        const int s111[3] = {1, 1, 1}, s222[3] = {2, 2, 2}, s444[3] = {4, 4, 4};
+        Act* cat = new_act("concatenator", B, T / 4, H / 4, W / 4, 14 * b);   // [deconv_pool2 2b | deconv_pool3 4b | deconv_pool4 8b]
+        Act* pools[3] = {nullptr, nullptr, nullptr};
+        build_gn_encoder(nullptr, [&](int stage, Act* in) {
+            if (stage == 1) gn_layer("deconv_pool2", true, in, 2 * b, k333, s111, new_view(cat, 0, 2 * b, ""), "deconv_pool2");
+            else gn_layer("deconv_pool3", true, in, 4 * b, k233, s222, new_view(cat, 2 * b, 4 * b, ""), "deconv_pool3");
+        }, pools);
+        gn_layer("deconv_pool4", true, pools[2], 8 * b, k133, s444, new_view(cat, 6 * b, 8 * b, ""), "deconv_pool4");
+        Act* z = gn_layer("conv_concat", false, cat, 16 * b, k333, s111, nullptr, "conv_concat");
+        z = gn_layer("decoder1_conv1", false, z, 4 * b, k333, s111, nullptr, "decoder1_conv1");
+        z = gn_layer("decoder1_deconv", true, z, 4 * b, k333, s222, nullptr, "decoder1_deconv");
+        z = gn_layer("decoder1_conv2", false, z, 2 * b, k333, s111, nullptr, "decoder1_conv2");
+        z = gn_layer("decoder2_conv1", false, z, b / 2, k333, s111, nullptr, "decoder2_conv1");
+        z = gn_layer("decoder2_deconv", true, z, b / 2, k333, s222, nullptr, "decoder2_deconv");
+        z = gn_layer("decoder2_conv2", false, z, b / 4, k333, s111, nullptr, "decoder2_conv2", /*dropout=*/true);
+        Param* kp = conv_weight("results/kernel", {3, 3, 3, b / 4, 1});
+        Param* bp = add_param("results/bias", {1}, true, INIT_ZEROS);
+        head(z, kp, bp, /*with_sigmoid=*/false, /*transpose=*/false);
     }
 
     // ---- the reference graph -------------------------------------------------------------------
@@ -1231,16 +1271,18 @@ struct p3d_handle {
 
     // results = sigmoid(conv3d_transpose(x, 1, 3, 2)) (p3d.py:217-219) + Smooth-L1 (train.py:156-159)
     bool head_sigmoid = true;
-    void head(Act* x, Param* k, Param* bias, bool with_sigmoid = true) {
+    // transpose = false: the stride-1 tf.layers.conv3d(x, 1, 3, 1, 'same') of gn/p3d_gn.py:537 instead
+    void head(Act* x, Param* k, Param* bias, bool with_sigmoid = true, bool transpose = true) {
         head_sigmoid = with_sigmoid;
-        logits = new_act("logits", x->N, 2 * x->D, 2 * x->H, 2 * x->W, 1, false);
-        pred = new_act("pred", x->N, 2 * x->D, 2 * x->H, 2 * x->W, 1, false);
+        const int up = transpose ? 2 : 1;
+        logits = new_act("logits", x->N, up * x->D, up * x->H, up * x->W, 1, false);
+        pred = new_act("pred", x->N, up * x->D, up * x->H, up * x->W, 1, false);
         d_dlogits = dalloc<float>(pred->rows());
         d_y = dalloc<float>(pred->rows());
         d_loss = dalloc<double>(1);
         char* xflag = consume(x);
         Op op;
-        op.name = "results"; op.kind = "head_deconv";
+        op.name = "results"; op.kind = transpose ? "head_deconv" : "head_conv";
         op.flops = 2.0 * x->rows() * 27 * x->C;
         op.bytes = 4.0 * (x->rows() * (double)x->C + 2.0 * pred->rows());
         op.bflops = 2 * op.flops; op.bbytes = 4.0 * (3.0 * x->rows() * (double)x->C + 2.0 * pred->rows());
@@ -1254,11 +1296,19 @@ struct p3d_handle {
             return a;
         };
         const double hf = op.flops, hb = op.bytes;
-        op.fwd = [=](const Ctx& c) { launch(c, "head_fwd_kernel", hf, hb, [&]() { return p3d_head_fwd(mk(), c.s); }); };
+        op.fwd = [=](const Ctx& c) {
+            if (transpose) launch(c, "head_fwd_kernel", hf, hb, [&]() { return p3d_head_fwd(mk(), c.s); });
+            else launch(c, "headc_fwd_kernel", hf, hb, [&]() { return p3d_headc_fwd(mk(), c.s); });
+        };
         op.bwd = [=](const Ctx& c) {
             if (*xflag) throw P3dError("head input gradient must be the first writer");
-            launch(c, "head_bwd_filter_kernel", hf, hb, [&]() { return p3d_head_bwd_filter(mk(), c.s); });
-            launch(c, "head_bwd_input_kernel", hf, hb, [&]() { return p3d_head_bwd_input(mk(), c.s); });
+            if (transpose) {
+                launch(c, "head_bwd_filter_kernel", hf, hb, [&]() { return p3d_head_bwd_filter(mk(), c.s); });
+                launch(c, "head_bwd_input_kernel", hf, hb, [&]() { return p3d_head_bwd_input(mk(), c.s); });
+            } else {
+                launch(c, "headc_bwd_filter_kernel", hf, hb, [&]() { return p3d_headc_bwd_filter(mk(), c.s); });
+                launch(c, "headc_bwd_input_kernel", hf, hb, [&]() { return p3d_headc_bwd_input(mk(), c.s); });
+            }
         };
         ops.push_back(op);
     }
@@ -1306,6 +1356,17 @@ struct p3d_handle {
         own_sufmin.assign(own_sorted.size(), 0);
         int m = (int)ops.size();
         for (size_t p = own_sorted.size(); p-- > 0;) { m = std::min(m, own_sorted[p].second); own_sufmin[p] = m; }
+        // brute-force check of the walk run_backward does: after op i, nothing at or above `lo` may belong to an
+        // op that has not run its backward yet (a premature all-reduce would silently drop gradient terms)
+        size_t pos = own_sorted.size();
+        for (int i = (int)ops.size() - 1; i >= 0; --i) {
+            while (pos > 0 && own_sufmin[pos - 1] >= i) --pos;
+            const int64_t lo = pos < own_sorted.size() ? own_sorted[pos].first : n_train;
+            for (auto& kv : owner)
+                if (kv.first->off >= lo && kv.second < i)
+                    throw P3dError("gradient bucket order broken at op " + ops[i].name + " / variable " + kv.first->name);
+        }
+        if (pos != 0) throw P3dError("gradient bucket walk does not reach offset 0");
     }
 
     // One forward + backward over garbage data with the kernels' autotuners switched on: every distinct conv
@@ -1508,13 +1569,14 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         HIPCHECK(hipEventCreateWithFlags(&h->ev_side_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_comm_done, hipEventDisableTiming));
-        if (cfg->structure < P3D_STRUCTURE_UNET || cfg->structure > P3D_STRUCTURE_UNETPP_NONSA) throw P3dError("unknown structure");
+        if (cfg->structure < P3D_STRUCTURE_UNET || cfg->structure > P3D_STRUCTURE_GN_P3D_DECODER) throw P3dError("unknown structure");
         if (cfg->batch < 1) throw P3dError("batch must be >= 1");
         for (int i = 0; i < 3; ++i)
             if (cfg->blocks[i] < 1) throw P3dError("blocks must be >= 1");
         if (cfg->structure == P3D_STRUCTURE_CONCAT) h->build_concat();
         else if (cfg->structure == P3D_STRUCTURE_GN_P3D) h->build_gn_p3d();
         else if (cfg->structure == P3D_STRUCTURE_UNETPP_NONSA) h->build_unetpp_nonsa();
+        else if (cfg->structure == P3D_STRUCTURE_GN_P3D_DECODER) h->build_gn_decoder();
         else h->build_unet();
         h->finalize_build();
         HIPCHECK(hipStreamSynchronize(h->stream));

@@ -210,6 +210,7 @@ struct CbamArgs {
     float* dpre;                                 // [M]
     float* dsp;                                  // [M][2]
     float* dcs_part;                             // [N][chunks][C]
+    float* dO;                                   // [N][C] gradient of the MLP output (pre-sigmoid)
     float* davg; float* dmx;                     // [N][C] gradients of the pooled vectors
     float* dh;                                   // [N][2][Ch] gradients of the hidden activations (avg, max branch)
     float* dx; int lddx; int accx;               // gradient of x
@@ -243,6 +244,10 @@ struct HeadArgs {
 hipError_t p3d_head_fwd(const HeadArgs& a, hipStream_t s);
 hipError_t p3d_head_bwd_input(const HeadArgs& a, hipStream_t s);    // dx written
 hipError_t p3d_head_bwd_filter(const HeadArgs& a, hipStream_t s);   // dk, dbias atomically added
+// the stride-1 variant tf.layers.conv3d(x, 1, 3, 1, 'same') (gn/p3d_gn.py:537): D,H,W are both input and output extents
+hipError_t p3d_headc_fwd(const HeadArgs& a, hipStream_t s);
+hipError_t p3d_headc_bwd_input(const HeadArgs& a, hipStream_t s);
+hipError_t p3d_headc_bwd_filter(const HeadArgs& a, hipStream_t s);
 
 // ---- loss: Smooth-L1 sum (utils/network.py:49-62, train.py:159) fused with sigmoid backward ---
 // loss_out: double accumulator (zeroed by caller).  dlogits = dL/dpred * pred*(1-pred).

@@ -36,6 +36,10 @@ CONV_CASES = [
     ((1, 3, 37, 41, 3), (1, 7, 7), 64, (1, 2, 2)),       # stem (Cin=3), odd extents
     ((2, 4, 32, 32, 3), (1, 7, 7), 16, (1, 2, 2)),       # stem, reduced width
     ((1, 1, 5, 5, 8), (1, 1, 1), 4, (1, 1, 1)),          # tiny
+    ((1, 4, 12, 12, 8), (3, 3, 3), 4, (1, 1, 1)),        # decoder2_conv2 of the GN decoder head at base 16: 8 -> 4 channels
+    ((1, 4, 12, 12, 32), (3, 3, 3), 8, (1, 1, 1)),       # decoder2_conv1
+    ((2, 3, 6, 6, 4), (3, 3, 3), 8, (1, 1, 1)),          # 4 input channels: one 16-byte chunk per row
+    ((1, 4, 10, 10, 8), (3, 3, 3), 8, (2, 2, 2)),        # input-gradient shape of decoder2_deconv
 ]
 
 
@@ -67,6 +71,8 @@ DECONV_CASES = [
     ((1, 2, 6, 5, 32), (3, 3, 3), 16, (2, 2, 2)),     # deconv3
     ((1, 1, 3, 3, 16), (3, 3, 3), 8, (4, 4, 4)),      # deconv_pool4 of the concat head: k < s
     ((1, 2, 5, 5, 16), (3, 3, 3), 8, (1, 1, 1)),      # deconv_pool2 of the concat head: stride 1
+    ((1, 1, 3, 3, 32), (1, 3, 3), 16, (4, 4, 4)),     # deconv_pool4 of the GN decoder head: k < s on every axis
+    ((1, 2, 6, 6, 8), (3, 3, 3), 8, (2, 2, 2)),       # decoder2_deconv at base 16
 ]
 
 

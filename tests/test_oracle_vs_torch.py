@@ -158,3 +158,34 @@ def test_gn_cbam_net_fp64():
     assert len(grads) == len([k for k in m.p if m.p[k].requires_grad])
     for n, gr in grads.items():
         assert rel_l2(gr, m.p[n].grad.numpy(), 1e-4 * scale) < 1e-8, n
+
+
+def test_gn_decoder_block_net_fp64():
+    """gn/p3d_gn.py:489 inference_p3d_decoder_block (net='P3D_DECODER': skip deconvs with k<s, two decoder
+    blocks, stride-1 conv to one channel, variables under scope 'P3D/') vs torch autograd."""
+    from oracle import p3d_gn
+    cfg = p3d.NetConfig(base=16, blocks=(1, 2, 2))
+    params = p3d_gn.init_params(1, cfg, dtype=np.float64, head='decoder')
+    assert all(k.startswith('P3D/') for k in params)
+    assert 'P3D/results/kernel' in params and params['P3D/results/kernel'].shape == (3, 3, 3, 4, 1)
+    assert params['P3D/deconv_pool4/kernel'].shape == (1, 3, 3, 128, 256)
+    rng = np.random.default_rng(7)
+    for k, v in params.items():
+        if k.endswith('gamma'):
+            v[:] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith(('beta', '/bias')):
+            v[:] = rng.uniform(-0.3, 0.3, v.shape)
+    x = p3d.synthetic_clip(0, (1, 16, 32, 32, 3)).astype(np.float64)
+    y = p3d.synthetic_target(3, (1, 16, 32, 32)).astype(np.float64)
+    loss, pred, grads, g = p3d_gn.loss_and_grads(params, x, y, 0.0, True, cfg, np.float64, head='decoder')
+    bare = {k[len('P3D/'):]: v for k, v in params.items()}
+    m = torch_ref.TorchP3DGN(bare, torch.float64, cfg.base, cfg.blocks)
+    tp = m.decoder_block(torch.tensor(x))
+    tl = torch_ref.smooth_l1_sum(tp.reshape(y.shape), torch.tensor(y))
+    tl.backward()
+    assert abs(loss - tl.item()) <= 1e-10 * abs(tl.item())
+    assert np.abs(pred - tp.detach().numpy()).max() < 1e-10
+    scale = np.median([np.linalg.norm(gr) for gr in grads.values()])
+    assert len(grads) == len([k for k in m.p if m.p[k].requires_grad])
+    for n, gr in grads.items():
+        assert rel_l2(gr, m.p[n[len('P3D/'):]].grad.numpy(), 1e-4 * scale) < 1e-8, n

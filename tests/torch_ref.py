@@ -269,3 +269,38 @@ class TorchP3DGN(TorchP3D):
         c = torch.relu(self.gn(conv3d_transpose_same(c, p['deconv_revise/kernel'], (2, 2, 2), p['deconv_revise/bias'])))
         c = conv3d_transpose_same(c, p['predict_revise/kernel'], (2, 2, 2), p['predict_revise/bias'])
         return c.permute(0, 2, 3, 4, 1)
+
+    def decoder_block(self, x_ndhwc):
+        """gn/p3d_gn.py:489-539 inference_p3d_decoder_block; parameter names WITHOUT the 'P3D/' scope prefix."""
+        p, b = self.p, self.base
+        x = x_ndhwc.permute(0, 4, 1, 2, 3)
+        x = torch.relu(self.gn(conv3d_same(x, p['firstconv1'], (1, 2, 2))))
+        x = max_pool_same(x, (2, 3, 3), (2, 2, 2))
+
+        def up(t, name, s):
+            return torch.relu(self.gn(conv3d_transpose_same(t, p[name + '/kernel'], s, p[name + '/bias'])))
+
+        def conv(t, name):
+            return torch.relu(self.gn(conv3d_same(t, p[name + '/kernel'], (1, 1, 1), p[name + '/bias'])))
+        i, inpl = 0, b
+        skips = []
+        for stage, (n, planes) in enumerate(zip(self.blocks, (b, 2 * b, 4 * b))):
+            if stage == 1:
+                skips.append(up(x, 'deconv_pool2', (1, 1, 1)))
+            if stage == 2:
+                skips.append(up(x, 'deconv_pool3', (2, 2, 2)))
+            for j in range(n):
+                x = self.block(x, i, inpl, planes, j == 0, stage > 0)
+                inpl = planes * 4
+                i += 1
+            x = max_pool_same(x, (2, 1, 1), (2, 1, 1))
+        skips.append(up(x, 'deconv_pool4', (4, 4, 4)))
+        c = conv(torch.cat(skips, 1), 'conv_concat')
+        c = conv(c, 'decoder1_conv1')
+        c = up(c, 'decoder1_deconv', (2, 2, 2))
+        c = conv(c, 'decoder1_conv2')
+        c = conv(c, 'decoder2_conv1')
+        c = up(c, 'decoder2_deconv', (2, 2, 2))
+        c = conv(c, 'decoder2_conv2')
+        c = conv3d_same(c, p['results/kernel'], (1, 1, 1), p['results/bias'])
+        return c.permute(0, 2, 3, 4, 1)
