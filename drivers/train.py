@@ -22,6 +22,7 @@ def get_arguments():
     p = argparse.ArgumentParser(description="P3D saliency trainer (MI355X-native)")
     p.add_argument("--normalization", type=str, default="bn", help="bn -> p3d.py graphs, gn -> gn/p3d_gn.py inference_p3d")
     p.add_argument("--structure", type=str, default="unet", help="unet | concat | unet++nonsa (train.py:149-154; unet++ without its attention blocks, p3d.py:401)")
+    p.add_argument("--net", type=str, default="P3D", help="with --normalization gn: P3D | P3D_CONCAT | P3D_DECODER (gn/train_p3d_gn_dataset.py:30,169-180)")
     p.add_argument("--batch", type=int, default=2)
     p.add_argument("--lr", type=float, default=1e-4)
     p.add_argument("--epoch", type=int, default=1)
@@ -54,7 +55,10 @@ def batches(args, rng):
 def main():
     args = get_arguments()
     from sap3d_tensorflow_amd import P3DSession
-    structure = "gn_p3d" if args.normalization == "gn" else args.structure
+    gn_nets = {"P3D": "gn_p3d", "P3D_CONCAT": "gn_p3d_concat", "P3D_DECODER": "gn_p3d_decoder"}     # gn/train_p3d_gn_dataset.py:169-180
+    if args.normalization == "gn" and args.net not in gn_nets:
+        raise SystemExit("--net %s is not built (attention heads, SURVEY.md row N2); have %s" % (args.net, sorted(gn_nets)))
+    structure = gn_nets[args.net] if args.normalization == "gn" else args.structure
     sess = P3DSession(structure, batch=args.batch, device=int(args.gpu), seed=0)      # graph + global_variables_initializer
     sess.set_adam(args.lr)
     model_dir = os.path.join("model", args.info)

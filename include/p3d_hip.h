@@ -30,10 +30,12 @@ enum {
     P3D_STRUCTURE_UNETPP_NONSA = 3, /* p3d.p3d_unetplusplus_nonsa (p3d.py:401): the nested UNet++ head of
                                     train.py:153-154 `--structure unet++` with its attention blocks left out
                                     (layer wrappers utils/network.py:97-110) */
-    P3D_STRUCTURE_GN_P3D_DECODER = 4 /* gn/train_p3d_gn_dataset.py:177-178 net='P3D_DECODER' ->
+    P3D_STRUCTURE_GN_P3D_DECODER = 4, /* gn/train_p3d_gn_dataset.py:177-178 net='P3D_DECODER' ->
                                     p3d_gn.inference_p3d_decoder_block (gn/p3d_gn.py:489): GN/CBAM encoder, skip
                                     deconvs + concat, two conv-deconv-conv decoder blocks, 3x3x3 conv to 1 channel;
                                     variables live in scope "P3D/"; base must be a multiple of 16 */
+    P3D_STRUCTURE_GN_P3D_CONCAT = 5 /* gn/train_p3d_gn_dataset.py:171-172 net='P3D_CONCAT' -> p3d_gn.inference_p3d_concat
+                                    (gn/p3d_gn.py:279): GN_P3D with deconv_pool4 at 8*base instead of 16*base filters */
 };
 
 typedef struct p3d_config {

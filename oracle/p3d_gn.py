@@ -151,8 +151,9 @@ class make_block():
         return x
 
 
-def inference_p3d(g, _X, _dropout, batch_size=2, training=True, cfg=None, keep_mask=None):
-    """gn/p3d_gn.py:214-258.  GroupNorm has no train/eval difference; `training` only gates dropout."""
+def inference_p3d(g, _X, _dropout, batch_size=2, training=True, cfg=None, keep_mask=None, pool4_filters=16):
+    """gn/p3d_gn.py:214-258.  GroupNorm has no train/eval difference; `training` only gates dropout.
+    pool4_filters (in units of cfg.base) is 16 here and 8 in inference_p3d_concat, the only difference."""
     cfg = cfg or REFERENCE_CFG
     t = g.tape
     b = cfg.base
@@ -174,7 +175,7 @@ def inference_p3d(g, _X, _dropout, batch_size=2, training=True, cfg=None, keep_m
     b3 = make_block(g, pool3, 4 * b, cfg.blocks[2], 8 * b, cnt, depth_3d=cfg.depth_3d, stride=2)
     res3 = b3.infer()
     pool4 = max_pool3d(g, res3, [1, 2, 1, 1, 1], [1, 2, 1, 1, 1])
-    deconv_pool4 = layers_conv3d_transpose(g, pool4, 16 * b, 3, [4, 4, 4], name='deconv_pool4')
+    deconv_pool4 = layers_conv3d_transpose(g, pool4, pool4_filters * b, 3, [4, 4, 4], name='deconv_pool4')
     deconv_pool4_gn = GNReLU(g, deconv_pool4)
     concatenator = nn.concat(t, [deconv_pool3_gn, deconv_pool4_gn, pool2])
     conv_concat = GNReLU(g, layers_conv3d(g, concatenator, 16 * b, 3, 1, name='conv_concat'))
@@ -183,6 +184,11 @@ def inference_p3d(g, _X, _dropout, batch_size=2, training=True, cfg=None, keep_m
     deconv1_revise = nn.dropout(t, deconv1_revise, _dropout, training, keep_mask)
     results = layers_conv3d_transpose(g, deconv1_revise, 1, 3, 2, name='predict_revise')
     return results
+
+
+def inference_p3d_concat(g, _X, _dropout, batch_size=2, training=True, cfg=None, keep_mask=None):
+    """gn/p3d_gn.py:279-324 (net='P3D_CONCAT'): inference_p3d with deconv_pool4 at 512 instead of 1024 filters."""
+    return inference_p3d(g, _X, _dropout, batch_size, training, cfg, keep_mask, pool4_filters=8)
 
 
 def conv3d_layers(g, x, filters, kernel, strides, name):
@@ -240,6 +246,7 @@ def inference_p3d_decoder_block(g, _X, _dropout, batch_size=2, training=True, cf
 
 
 HEADS = {'p3d': inference_p3d,                         # gn/train_p3d_gn_dataset.py:169-170  net='P3D'
+         'concat': inference_p3d_concat,               # gn/train_p3d_gn_dataset.py:171-172  net='P3D_CONCAT'
          'decoder': inference_p3d_decoder_block}       # gn/train_p3d_gn_dataset.py:177-178  net='P3D_DECODER'
 
 

@@ -985,17 +985,19 @@ struct p3d_handle {
         return gn_apply(std::string(name) + "_gn", 0, y, g, nullptr, nullptr, out, out_name, dropout);
     }
 
-    // inference_p3d (gn/p3d_gn.py:214-258)
-    void build_gn_p3d() {
+    // inference_p3d (gn/p3d_gn.py:214-258; pool4_filters = 16) and inference_p3d_concat (gn/p3d_gn.py:279-324;
+    // pool4_filters = 8, the only difference), filters in units of base
+    void build_gn_p3d(int pool4_filters) {
         const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
         const int k333[3] = {3, 3, 3}, s111[3] = {1, 1, 1}, s222[3] = {2, 2, 2}, s444[3] = {4, 4, 4};
-        // concatenator = [deconv_pool3_gn (8b) | deconv_pool4_gn (16b) | pool2 (4b)]  (gn/p3d_gn.py:251)
-        Act* cat = new_act("concatenator", B, T / 4, H / 4, W / 4, 28 * b);
+        // concatenator = [deconv_pool3_gn (8b) | deconv_pool4_gn (16b or 8b) | pool2 (4b)]  (gn/p3d_gn.py:251,317)
+        const int p4 = pool4_filters * b;
+        Act* cat = new_act("concatenator", B, T / 4, H / 4, W / 4, 12 * b + p4);
         Act* pools[3] = {nullptr, nullptr, nullptr};
-        build_gn_encoder(new_view(cat, 24 * b, 4 * b, "pool2"), [&](int stage, Act* in) {
+        build_gn_encoder(new_view(cat, 8 * b + p4, 4 * b, "pool2"), [&](int stage, Act* in) {
             if (stage == 2) gn_layer("deconv_pool3", true, in, 8 * b, k333, s222, new_view(cat, 0, 8 * b, ""), "");   // before stage 3
         }, pools);
-        gn_layer("deconv_pool4", true, pools[2], 16 * b, k333, s444, new_view(cat, 8 * b, 16 * b, ""), "");
+        gn_layer("deconv_pool4", true, pools[2], p4, k333, s444, new_view(cat, 8 * b, p4, ""), "");
         Act* zc = gn_layer("conv_concat", false, cat, 16 * b, k333, s111, nullptr, "conv_concat");
         Act* zr = gn_layer("deconv_revise", true, zc, 4 * b, k333, s222, nullptr, "deconv_revise", /*dropout=*/true);
         Param* kp = conv_weight("predict_revise/kernel", {3, 3, 3, 1, 4 * b});
@@ -1569,12 +1571,13 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         HIPCHECK(hipEventCreateWithFlags(&h->ev_side_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_comm_done, hipEventDisableTiming));
-        if (cfg->structure < P3D_STRUCTURE_UNET || cfg->structure > P3D_STRUCTURE_GN_P3D_DECODER) throw P3dError("unknown structure");
+        if (cfg->structure < P3D_STRUCTURE_UNET || cfg->structure > P3D_STRUCTURE_GN_P3D_CONCAT) throw P3dError("unknown structure");
         if (cfg->batch < 1) throw P3dError("batch must be >= 1");
         for (int i = 0; i < 3; ++i)
             if (cfg->blocks[i] < 1) throw P3dError("blocks must be >= 1");
         if (cfg->structure == P3D_STRUCTURE_CONCAT) h->build_concat();
-        else if (cfg->structure == P3D_STRUCTURE_GN_P3D) h->build_gn_p3d();
+        else if (cfg->structure == P3D_STRUCTURE_GN_P3D) h->build_gn_p3d(16);
+        else if (cfg->structure == P3D_STRUCTURE_GN_P3D_CONCAT) h->build_gn_p3d(8);
         else if (cfg->structure == P3D_STRUCTURE_UNETPP_NONSA) h->build_unetpp_nonsa();
         else if (cfg->structure == P3D_STRUCTURE_GN_P3D_DECODER) h->build_gn_decoder();
         else h->build_unet();

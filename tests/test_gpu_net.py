@@ -265,16 +265,22 @@ def _gn_params(cfg, dtype, head='p3d'):
     return params
 
 
-@pytest.mark.parametrize("cfg,shape", GN_SMALL)
-def test_gn_cbam_forward_backward(cfg, shape):
+# (config index, head, gradient allowance for deterministic ReLU sign flips; see test_gn_decoder_block_forward_backward)
+GN_CASES = [(0, 'p3d', 0.0), (1, 'p3d', 0.0), (0, 'concat', 0.0), (1, 'concat', 1.5e-2)]
+
+
+@pytest.mark.parametrize("ci,head,flip_allowance", GN_CASES)
+def test_gn_cbam_forward_backward(ci, head, flip_allowance):
+    """net='P3D' (gn/p3d_gn.py:214) and net='P3D_CONCAT' (gn/p3d_gn.py:279, deconv_pool4 at half the filters)."""
+    cfg, shape = GN_SMALL[ci]
     from oracle import p3d_gn
-    p64 = _gn_params(cfg, np.float64)
+    p64 = _gn_params(cfg, np.float64, head)
     p32 = {k: v.astype(np.float32) for k, v in p64.items()}
     x = p3d.synthetic_clip(0, shape + (3,))
     y = p3d.synthetic_target(3, shape)
-    s = make_session(cfg, shape, p32, 'gn_p3d')
+    s = make_session(cfg, shape, p32, 'gn_p3d' if head == 'p3d' else 'gn_p3d_concat')
     assert [n for n, _, _ in s.variables()] == list(p64)
-    want, g = p3d_gn.forward(p64, x.astype(np.float64), 0.0, False, cfg, np.float64)
+    want, g = p3d_gn.forward(p64, x.astype(np.float64), 0.0, False, cfg, np.float64, head=head)
     got = s.forward(x, 0.0, False)
     for name in ['conv1_custom_bn_relu', 'block0/conv1_bn_relu', 'block0/st', 'block0/out', 'block1/out', 'block2/out',
                  'conv_concat']:
@@ -283,8 +289,8 @@ def test_gn_cbam_forward_backward(cfg, shape):
         assert a.shape == w.shape, name
         assert np.abs(a - w).max() <= 1e-4 * max(np.abs(w).max(), 1.0), name
     assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)
-    l64, pr64, g64, _ = p3d_gn.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True, cfg, np.float64)
-    l32, _, g32, _ = p3d_gn.loss_and_grads(dict(p32), x, y, 0.0, True, cfg, np.float32)
+    l64, pr64, g64, _ = p3d_gn.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True, cfg, np.float64, head=head)
+    l32, _, g32, _ = p3d_gn.loss_and_grads(dict(p32), x, y, 0.0, True, cfg, np.float32, head=head)
     scale = np.median([np.linalg.norm(v) for v in g64.values()])
     floor = 1e-2 * scale
     # CBAM routes gradients through arg-max selections (over positions and over channels).  At this size one
@@ -299,7 +305,7 @@ def test_gn_cbam_forward_backward(cfg, shape):
         errs = {n: rel_l2(s.get_grad(n), w, floor) for n, w in g64.items()}
         for n, e in errs.items():
             assert e <= 3e-2, (attempt, n, e)
-        if all(e <= 5 * rel_l2(g32[n], g64[n], floor) + 2e-3 for n, e in errs.items()):
+        if all(e <= 5 * rel_l2(g32[n], g64[n], floor) + 2e-3 + flip_allowance for n, e in errs.items()):
             tight = True
             break
     assert tight, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
