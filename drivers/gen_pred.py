@@ -6,7 +6,8 @@ every later window only its last map (gen_pred.py:154-168); frames are normalise
 ((RGB - [90,102,98]) / 255 after resizing to 112x112).  The reference decodes JPEG folders with cv2 and writes
 960x1080 JPEGs; cv2 is outside this path, so a video here is a .npy array [F,H,W,3] uint8 RGB and the maps come
 back as a float32 array [F,112,112].  Stride-1 windows are batched (`--batch`) instead of run one by one:
-identical results, B windows per launch."""
+`p3d_predict_windows` gives every window the result of its own batch-of-1 run (the backbone BatchNorm uses batch
+statistics even at inference, p3d.py:140, so a plain batched forward would couple the windows)."""
 import argparse
 import glob
 import os
@@ -47,7 +48,7 @@ def predict_video(sess, frames, batch):
     for i in range(0, len(starts), batch):
         chunk = starts[i:i + batch]
         clips = np.stack([frames[s:s + 16] for s in chunk] + [frames[chunk[-1]:chunk[-1] + 16]] * (batch - len(chunk)))
-        maps = sess.forward(clips, dropout=0.0, training=False)[..., 0]
+        maps = sess.predict_windows(clips)[..., 0]       # = B batch-of-1 forwards (gen_pred.py:151), see include/p3d_hip.h
         for k, s in enumerate(chunk):
             if s == 0:
                 out[:16] = maps[k]            # first window: all 16 maps

@@ -75,6 +75,14 @@ int p3d_init_params(p3d_handle* h, uint64_t seed);
  *      (p3d.py:140,179,185,191).  Never updates moving statistics (UPDATE_OPS are not fetched). */
 int p3d_forward(p3d_handle* h, const float* x, int training, float dropout_rate, uint64_t seed, float* pred);
 
+/* ---- B sliding windows of gen_pred.py:100-168 in one pass.  The reference runs sess.run(pred, ...) once per
+ *      window with a batch of ONE clip (gen_pred.py:45,151), so the backbone's batch-statistics BatchNorm
+ *      (p3d.py:140) sees one clip at a time.  This entry point takes `batch` windows x [B,T,H,W,3] and returns for
+ *      each exactly what a batch-of-1 p3d_forward(training=0, dropout=0) returns for it: every batch-statistics
+ *      BN normalises each clip with that clip's own statistics.  (For the GroupNorm structures it equals
+ *      p3d_forward, GN has no cross-clip coupling.) */
+int p3d_predict_windows(p3d_handle* h, const float* x, float* pred);
+
 /* ---- sess.run([train_op, loss], {x, y, dropout, training: True})   train.py:217-218.
  *      y [B,T,H,W]; Smooth-L1 SUM loss (utils/network.py:49-62), Adam on every trainable
  *      (train.py:168), BN moving-average updates (train.py:170-172).  With world_size > 1 the

@@ -5,7 +5,7 @@
 // The reference transposes to NCDHW and back around every GroupNorm; here nothing moves: per-(sample,
 // channel) sums are reduced where the data lies, a finalize pass folds the C/G channels of a group and emits
 // per-(sample, channel) scale/shift tables, and the apply pass is the BatchNorm apply with a table row per
-// sample.  Modes: 0 relu(gn(y1)); 1 relu(gn(y1) + r); 3 relu(gn(y1)) + relu(gn(y2)) (ST_B);
+// sample.  Modes: 0 relu(gn(y1)); 1 relu(gn(y1) + r); 2 relu(gn(y1) + gn(y2)) (forward only); 3 relu(gn(y1)) + relu(gn(y2)) (ST_B);
 // 4 r + relu(gn(y1)) (ST_C); 5 gn(y1); 6 relu(gn(y1) + r * cs[n,c] * ss[pos]) (CBAM-scaled residual,
 // gn/p3d_gn.py:175-177 with utils/network.py:249,274 folded in).
 #include "p3d_kernels.h"
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
         if (MODE == 0) z = relu4(v);
         else if (MODE == 5) z = v;
         else if (MODE == 1) z = relu4(add4(v, ld4(a.y2 + row * a.ld2 + c)));
+        else if (MODE == 2) z = relu4(add4(v, fma4(ld4(a.g2.scale + t), ld4(a.y2 + row * a.ld2 + c), ld4(a.g2.shift + t))));   // forward only
         else if (MODE == 3) z = add4(relu4(v), relu4(fma4(ld4(a.g2.scale + t), ld4(a.y2 + row * a.ld2 + c), ld4(a.g2.shift + t))));
         else if (MODE == 4) z = add4(ld4(a.y2 + row * a.ld2 + c), relu4(v));
         else z = relu4(add4(v, mul4(mul4(ld4(a.y2 + row * a.ld2 + c), ld4(a.cs + t)), f4(a.ss[row]))));
@@ -280,6 +281,9 @@ hipError_t p3d_gn_finalize(const GnParams& p, int N, int R, float eps, hipStream
 hipError_t p3d_gn_apply(const GnApplyArgs& a, hipStream_t s) {
     if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
     const dim3 g(grid_for(a.M * (a.C >> 2)));
+    // mode 2 = relu(norm1(y1) + norm2(y2)): the projected residual of the BatchNorm bottleneck normalised per
+    // sample (p3d_predict_windows); it has no backward
+    if (a.mode == 2) { hipLaunchKernelGGL(gn_apply_kernel<2>, g, dim3(256), 0, s, a); return hipGetLastError(); }
     P3D_GN_SWITCH(gn_apply_kernel, g)
     return hipGetLastError();
 }

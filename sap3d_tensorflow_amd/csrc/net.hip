@@ -115,6 +115,7 @@ struct Ctx {
     float drop = 0.f;
     uint64_t seed = 0;
     bool update_moving = false;
+    bool per_sample = false;          // batch-statistics BNs normalise every clip by its own statistics (p3d_predict_windows)
     hipStream_t s = nullptr;
     Prof* prof = nullptr;
     hipStream_t side = nullptr;       // weight gradients run here, off the backward critical path
@@ -512,6 +513,17 @@ struct p3d_handle {
         return f;
     }
 
+    // scratch of the per-sample BatchNorm inference path: two (sum, sumsq) tables and two scale/shift/mean/invstd
+    // tables of [batch][widest BN]; ops run one after another on one stream, so they can share it
+    double* ps_sums = nullptr; float* ps_tab = nullptr; int64_t ps_nc = 0;
+    void ensure_per_sample_scratch() {
+        if (ps_sums) return;
+        int cmax = 4;
+        for (auto& bn : bns) cmax = std::max(cmax, bn.C);
+        ps_nc = (int64_t)cfg.batch * cmax;
+        ps_sums = dalloc<double>(2 * 2 * ps_nc);
+        ps_tab = dalloc<float>(2 * 4 * ps_nc);
+    }
     BN* add_bn(const std::string& name_or_empty, int C, bool follows_flag) {
         bns.emplace_back();
         BN* bn = &bns.back();
@@ -663,7 +675,36 @@ struct p3d_handle {
         };
         const std::string kn_sf = "bn_small_fwd_kernel<" + std::to_string(mode) + ">";
         const std::string kn_sb = "bn_small_bwd_kernel<" + std::to_string(mode) + ">";
+        const int R = y1->D * y1->H * y1->W;
         op.fwd = [=](const Ctx& c) {
+            if (c.per_sample && (bn1->follows_flag ? c.training : true)) {
+                // B independent batch-of-1 normalisations: per-(clip, channel) statistics over D*H*W, i.e. the
+                // GroupNorm machinery with one channel per group and BN's epsilon
+                if (c.training || c.update_moving || dropout) throw P3dError("per-sample BatchNorm is an inference path");
+                ensure_per_sample_scratch();
+                auto norm = [&](BN* bn, Act* y, int slot) {
+                    GnParams p;
+                    memset(&p, 0, sizeof(p));
+                    const int64_t nc = (int64_t)y->N * C;
+                    p.gamma = bn->gamma->p; p.beta = bn->beta->p; p.C = C; p.G = C;
+                    p.sums = ps_sums + (int64_t)slot * 2 * ps_nc;
+                    float* t = ps_tab + (int64_t)slot * 4 * ps_nc;
+                    p.scale = t; p.shift = t + nc; p.mean = t + 2 * nc; p.invstd = t + 3 * nc;
+                    if (!c.dry) HIPCHECK(hipMemsetAsync(p.sums, 0, (size_t)nc * 2 * sizeof(double), c.s));
+                    launch(c, "gn_stats_kernel", 0, tens, [&]() { return p3d_gn_stats(y->p, y->ld, y->N, R, C, p.sums, c.s); });
+                    launch(c, "gn_finalize_kernel", 0, 32.0 * nc, [&]() { return p3d_gn_finalize(p, y->N, R, 1e-3f, c.s); });
+                    return p;
+                };
+                GnApplyArgs a;
+                memset(&a, 0, sizeof(a));
+                a.mode = mode; a.M = M; a.R = R; a.C = C;
+                a.y1 = y1->p; a.ld1 = y1->ld; a.g1 = norm(bn1, y1, 0);
+                if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; }
+                if (two) a.g2 = norm(bn2, y2, 1);
+                a.z = out->p; a.ldz = out->ld;
+                launch(c, "gn_apply_kernel(per-sample BN)", 0, tens * (y2 ? 3 : 2), [&]() { return p3d_gn_apply(a, c.s); });
+                return;
+            }
             if (small) {
                 bn1->used_batch = bn1->follows_flag ? c.training : true;
                 if (two) bn2->used_batch = bn2->follows_flag ? c.training : true;
@@ -1711,6 +1752,17 @@ int p3d_forward(p3d_handle* h, const float* x, int training, float dropout_rate,
     HIPCHECK(hipSetDevice(h->cfg.device));
     h->upload(x, nullptr);
     Ctx c; c.training = training != 0; c.drop = dropout_rate; c.seed = seed; c.update_moving = false; c.s = h->stream;
+    h->run_forward(c);
+    h->download_act(h->pred, pred);
+    API_END
+}
+
+int p3d_predict_windows(p3d_handle* h, const float* x, float* pred) {
+    API_BEGIN
+    if (!h || !x || !pred) throw P3dError("null argument");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    h->upload(x, nullptr);
+    Ctx c; c.training = false; c.drop = 0.f; c.update_moving = false; c.per_sample = true; c.s = h->stream;
     h->run_forward(c);
     h->download_act(h->pred, pred);
     API_END

@@ -117,6 +117,14 @@ class P3DSession:
         check(lib().p3d_forward(self._h, fptr(x), int(bool(training)), float(dropout), seed, fptr(pred)))
         return pred
 
+    def predict_windows(self, x):
+        """B windows of gen_pred.py:100-168 at once: row k equals forward(x[k:k+1], training=False) of a batch-1
+        session, i.e. every batch-statistics BN normalises each clip by its own statistics."""
+        x = self._x(x)
+        pred = np.empty(self.pred_shape, np.float32)
+        check(lib().p3d_predict_windows(self._h, fptr(x), fptr(pred)))
+        return pred
+
     def train_step(self, x, y, dropout=0.5, seed=0):
         """sess.run([train_op, loss], {x, y, dropout, training: True})  (train.py:217-218) -> loss."""
         x, y = self._x(x), self._y(y)

@@ -417,3 +417,34 @@ def test_odd_batches_and_clip_shapes(shape):
         floor = 1e-2 * scale
         assert rel_l2(s.get_grad(n), w, floor) <= 5 * rel_l2(g32[n], w, floor) + 3e-3, n
     s.close()
+
+
+def test_predict_windows_equals_batch_of_one_forwards():
+    """gen_pred.py:100-168 runs one window per sess.run with a batch of one clip, and the backbone BN uses batch
+    statistics even at inference (p3d.py:140).  p3d_predict_windows batches B windows and must return for each
+    what its own batch-of-1 forward returns -- checked against the HIP batch-1 session and the fp64 oracle."""
+    cfg = p3d.NetConfig(base=16, blocks=(2, 2, 3))
+    T, H, W = 16, 48, 48
+    p64 = randomise_norm_params(p3d.init_params(1, 'unet', cfg, dtype=np.float64))
+    rng = np.random.default_rng(3)
+    for k, v in p64.items():            # non-trivial moving statistics for the stem / decoder BNs
+        if k.endswith('moving_mean'):
+            v[:] = rng.uniform(-0.2, 0.2, v.shape)
+        elif k.endswith('moving_variance'):
+            v[:] = rng.uniform(0.5, 1.5, v.shape)
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    video = p3d.synthetic_clip(5, (1, T + 2, H, W, 3))[0]
+    windows = np.stack([video[s:s + T] for s in range(3)])          # three stride-1 windows
+    sb = make_session(cfg, (3, T, H, W), p32)
+    batched = sb.predict_windows(windows)
+    coupled = sb.forward(windows, 0.0, False)
+    sb.close()
+    s1 = make_session(cfg, (1, T, H, W), p32)
+    for k in range(3):
+        single = s1.forward(windows[k:k + 1], 0.0, False)
+        assert np.abs(batched[k] - single[0]).max() < 2e-5, k
+        want, _ = p3d.forward(p64, windows[k:k + 1].astype(np.float64), 0.0, False, 'unet', cfg, np.float64)
+        assert np.abs(batched[k] - want[0]).max() < 1e-4, k
+    s1.close()
+    # and it matters: a plain batched forward couples the windows through the batch statistics
+    assert np.abs(coupled - batched).max() > 1e-3
