@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU (BASELINE.json config: batch 8 per MI355X)")
-    ap.add_argument("--structure", default="unet", choices=["unet", "concat", "gn_p3d", "unet++nonsa", "gn_p3d_decoder", "gn_p3d_concat"],
+    ap.add_argument("--structure", default="unet", choices=["unet", "concat", "gn_p3d", "unet++nonsa", "gn_p3d_decoder", "gn_p3d_concat", "unet++ds"],
                     help="graph to time (default: the BASELINE.json headline, p3d_unet)")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=112, help="clip height = width (BASELINE configs[4] uses 32 frames of 224)")
@@ -180,8 +180,9 @@ def main():
                                      "gn_p3d": "p3d_gn.inference_p3d (GroupNorm + CBAM)",
                                      "unet++nonsa": "p3d_unetplusplus_nonsa (nested UNet++ head, no attention)",
                                      "gn_p3d_decoder": "p3d_gn.inference_p3d_decoder_block (GroupNorm + CBAM, decoder blocks)",
-                                     "gn_p3d_concat": "p3d_gn.inference_p3d_concat (GroupNorm + CBAM)"}[args.structure], T, S, S, B,
-                                    {"unet": "BASELINE.json configs[2]", "gn_p3d": "BASELINE.json configs[3] graph, 1 GPU"}.get(args.structure, "SURVEY.md row N1")),
+                                     "gn_p3d_concat": "p3d_gn.inference_p3d_concat (GroupNorm + CBAM)",
+                                     "unet++ds": "p3d_unetplusplus_ds (nested UNet++ head with self attention)"}[args.structure], T, S, S, B,
+                                    {"unet": "BASELINE.json configs[2]", "gn_p3d": "BASELINE.json configs[3] graph, 1 GPU"}.get(args.structure, "SURVEY.md row N2" if args.structure == "unet++ds" else "SURVEY.md row N1")),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "dropout": 0.5},
             "model_tflops": round(value * FLOP_PER_CLIP_FWD_BWD * (T / 16.0) * (S / 112.0) ** 2 / 1e12, 2) if args.structure == "unet" else None,
             "final_loss": loss,

@@ -34,8 +34,13 @@ enum {
                                     p3d_gn.inference_p3d_decoder_block (gn/p3d_gn.py:489): GN/CBAM encoder, skip
                                     deconvs + concat, two conv-deconv-conv decoder blocks, 3x3x3 conv to 1 channel;
                                     variables live in scope "P3D/"; base must be a multiple of 16 */
-    P3D_STRUCTURE_GN_P3D_CONCAT = 5 /* gn/train_p3d_gn_dataset.py:171-172 net='P3D_CONCAT' -> p3d_gn.inference_p3d_concat
+    P3D_STRUCTURE_GN_P3D_CONCAT = 5, /* gn/train_p3d_gn_dataset.py:171-172 net='P3D_CONCAT' -> p3d_gn.inference_p3d_concat
                                     (gn/p3d_gn.py:279): GN_P3D with deconv_pool4 at 8*base instead of 16*base filters */
+    P3D_STRUCTURE_UNETPP_DS = 6   /* p3d.p3d_unetplusplus_ds (p3d.py:340): the UNet++ head WITH self attention
+                                    (utils/network.py:157-192) on x_4_0, x_3_1, x_2_2 and, keys/values pooled by 2,
+                                    x_1_3.  (train.py:153-154 wires p3d_unetplusplus, p3d.py:280, whose last
+                                    attention call adds tensors of different shapes and cannot be built.)
+                                    base must be a multiple of 16 */
 };
 
 typedef struct p3d_config {

@@ -292,6 +292,9 @@ def mul(tape, a, b):
     out = Var(a.data * b.data)
 
     def _unb(g, shape):
+        lead = g.ndim - len(shape)              # numpy broadcasting aligns trailing axes
+        if lead:
+            g = g.sum(axis=tuple(range(lead)))
         axes = tuple(i for i, (gs, s) in enumerate(zip(g.shape, shape)) if s == 1 and gs != 1)
         return g.sum(axis=axes, keepdims=True) if axes else g
 
@@ -425,6 +428,34 @@ def reduce_max(tape, x, axes):
         if out.grad is not None:
             ind = (x.data == m).astype(x.data.dtype)
             x.acc(ind / ind.sum(axis=tuple(axes), keepdims=True) * out.grad)
+    tape.record(bwd)
+    return out
+
+
+def matmul(tape, a, b, transpose_b=False):
+    """tf.matmul on [batch, m, k] x [batch, k, n] (or [batch, n, k] with transpose_b); utils/network.py:183,185."""
+    bd = np.swapaxes(b.data, -1, -2) if transpose_b else b.data
+    out = Var(np.matmul(a.data, bd))
+
+    def bwd():
+        if out.grad is None:
+            return
+        a.acc(np.matmul(out.grad, np.swapaxes(bd, -1, -2)))
+        gb = np.matmul(np.swapaxes(a.data, -1, -2), out.grad)
+        b.acc(np.swapaxes(gb, -1, -2) if transpose_b else gb)
+    tape.record(bwd)
+    return out
+
+
+def softmax(tape, x):
+    """tf.nn.softmax(x, axis=-1) (utils/network.py:184)."""
+    e = np.exp(x.data - x.data.max(axis=-1, keepdims=True))
+    y = e / e.sum(axis=-1, keepdims=True)
+    out = Var(y)
+
+    def bwd():
+        if out.grad is not None:
+            x.acc(y * (out.grad - (out.grad * y).sum(axis=-1, keepdims=True)))
     tape.record(bwd)
     return out
 

@@ -390,8 +390,86 @@ def p3d_unetplusplus_nonsa(g, _X, _dropout, batch_size=2, training=True, cfg=Non
     return nn.sigmoid(t, x_0_1)
 
 
+def attention(g, x, name, training, subsample=False, sub_size=2):
+    """utils/network.py:157-192 (SAGAN-style self attention, mode='bn').  f, g, h are unnamed tf.layers.conv3d
+    inside variable_scope(name) -> name/conv3d, name/conv3d_1, name/conv3d_2; the output conv is an unnamed
+    top-level tf.layers.conv3d (conv3d, conv3d_1, ... in call order), its BatchNorm an unnamed top-level
+    batch_normalization that follows `training`; the mixing scalar is the top-level variable 'gamma'+name,
+    initialised to 0.  Python-2 integer divisions (sub_size/2, each*2/sub_size) are written as //.
+    pool3d = tf.layers.max_pooling3d(v, s, s), 'valid' (utils/network.py:6-7); size 1 is the identity."""
+    t = g.tape
+    B, D, H, W, ch = x.data.shape
+    inter = max(1, ch // 8)
+    f = layers_conv3d(g, x, inter, 1, 1, name=name + '/conv3d')
+    gq = layers_conv3d(g, x, inter, 1, 1, name=name + '/conv3d_1')
+    h = layers_conv3d(g, x, ch, 1, 1, name=name + '/conv3d_2')
+    if subsample:
+        def pool3d(v, s):
+            if s == 1:
+                return v
+            assert all(e % s == 0 for e in v.data.shape[1:4]), "valid pooling = SAME pooling only for divisible extents"
+            return nn.max_pool3d(t, v, (s, s, s), (s, s, s))
+        f = pool3d(f, sub_size)
+        gq = pool3d(gq, sub_size // 2)
+        h = pool3d(h, sub_size)
+    flat = lambda v: nn.reshape(t, v, (B, -1, v.data.shape[-1]))            # hw_flatten, utils/network.py:194-195
+    s = nn.matmul(t, flat(gq), flat(f), transpose_b=True)
+    beta = nn.softmax(t, s)
+    o = nn.matmul(t, beta, flat(h))
+    o = nn.reshape(t, o, (B,) + tuple(e * 2 // sub_size for e in (D, H, W)) + (ch,))
+    o = layers_conv3d(g, o, ch, 1, sub_size // 2)                          # unnamed, top level
+    o = nn.relu(t, batch_normalization(g, o, training))
+    gamma = g.variable('gamma' + name, (1,), g.zeros)
+    return nn.add(t, nn.mul(t, o, gamma), x)
+
+
+def p3d_unetplusplus_ds(g, _X, _dropout, batch_size=2, training=True, cfg=None, keep_mask=None):
+    """p3d.py:340-397: the UNet++ head WITH self attention that can actually be built (p3d_unetplusplus, p3d.py:280,
+    adds a quarter-resolution tensor to a full-resolution one at p3d.py:334 and cannot).
+    = p3d_unetplusplus_nonsa + attention on x_4_0, x_3_1, x_2_2 (full) and x_1_3 (keys/values pooled by 2)."""
+    cfg = cfg or REFERENCE_CFG
+    t = g.tape
+    b = cfg.base
+    stem, x_2_0, x_3_0, x_4_0 = _encoder(g, _X, training, cfg)
+    x_1_0 = max_pool3d(g, stem, [1, 2, 1, 1, 1], [1, 2, 1, 1, 1])
+
+    def transpose_conv3d(x, channel, kernel, strides, name):
+        y = layers_conv3d_transpose(g, x, channel, kernel, strides, name=name)
+        return t.tap(name, nn.relu(t, batch_normalization(g, y, training)))
+
+    def conv3d(x, channel, kernel, strides, name):
+        y = layers_conv3d(g, x, channel, kernel, strides, name=name)
+        return t.tap(name, nn.relu(t, batch_normalization(g, y, training)))
+
+    def concat(xs):
+        return nn.concat(t, xs)
+
+    def sa(x, name, **kw):
+        return t.tap(name, attention(g, x, name, training, **kw))
+    x_4_0 = sa(x_4_0, 'x_4_0_sa')
+    upx_4_0 = transpose_conv3d(x_4_0, 8 * b, [1, 3, 3], [2, 2, 2], 'upx_4_0')
+    x_3_1 = conv3d(concat([x_3_0, upx_4_0]), 8 * b, [2, 3, 3], [1, 1, 1], 'x_3_1')
+    x_3_1 = sa(x_3_1, 'x_3_1_sa')
+    upx_3_0 = transpose_conv3d(x_3_0, 4 * b, [2, 3, 3], [2, 2, 2], 'upx_3_0')
+    x_2_1 = conv3d(concat([x_2_0, upx_3_0]), 4 * b, [3, 3, 3], [1, 1, 1], 'x_2_1')
+    upx_3_1 = transpose_conv3d(x_3_1, 4 * b, [2, 3, 3], [2, 2, 2], 'upx_3_1')
+    x_2_2 = conv3d(concat([x_2_1, upx_3_1]), 4 * b, [3, 3, 3], [1, 1, 1], 'x_2_2')
+    x_2_2 = sa(x_2_2, 'x_2_2_sa')
+    upx_2_0 = transpose_conv3d(x_2_0, 2 * b, [3, 3, 3], [2, 2, 2], 'upx_2_0')
+    x_1_1 = conv3d(concat([x_1_0, upx_2_0]), 2 * b, [3, 3, 3], [1, 1, 1], 'x_1_1')
+    upx_2_1 = transpose_conv3d(x_2_1, 2 * b, [3, 3, 3], [2, 2, 2], 'upx_2_1')
+    x_1_2 = conv3d(concat([x_1_1, upx_2_1]), 2 * b, [3, 3, 3], [1, 1, 1], 'x_1_2')
+    upx_2_2 = transpose_conv3d(x_2_2, 2 * b, [3, 3, 3], [2, 2, 2], 'upx_2_2')
+    x_1_3 = conv3d(concat([x_1_2, upx_2_2]), 2 * b, [3, 3, 3], [1, 1, 1], 'x_1_3')
+    x_1_3 = sa(x_1_3, 'x_1_3_sa', subsample=True)
+    x_1_3 = nn.dropout(t, x_1_3, _dropout, training, keep_mask)
+    x_0_1 = layers_conv3d_transpose(g, x_1_3, 1, 3, 2, name='x_0_1')
+    return nn.sigmoid(t, x_0_1)
+
+
 STRUCTURES = {'unet': p3d_unet, 'concat': p3d_concat,      # train.py:149-154
-              'unet++nonsa': p3d_unetplusplus_nonsa}       # p3d.py:401 (unet++ minus attention)
+              'unet++nonsa': p3d_unetplusplus_nonsa,       # p3d.py:401 (unet++ minus attention)
+              'unet++ds': p3d_unetplusplus_ds}             # p3d.py:340 (unet++ with the attention blocks that build)
 
 
 # ---------------------------------------------------------------------------

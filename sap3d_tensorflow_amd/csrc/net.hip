@@ -367,6 +367,30 @@ WgradArgs wgrad_conv(const ConvGeo& g, int N, const float* x, int ldx, int Cin, 
     return a;
 }
 
+// A plain row-major GEMM  Y[M x Nc] = X[M x K] * W  as a 1x1x1 convolution over one clip's lattice (D,H,W),
+// M = D*H*W (the kernels pack lattice coordinates, so M is passed as the lattice it came from).
+// W is [K][Nc] (wT = 0) or [Nc][K] (wT = 1), dense.
+IgemmArgs gemm_rows(int D, int H, int W, const float* x, int ldx, int K, const float* w, int wT, float* y, int ldy, int Nc) {
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.N = 1; a.Di = D; a.Hi = H; a.Wi = W; a.ldx = ldx; a.K = K;
+    a.Gd = D; a.Gh = H; a.Gw = W; a.isd = a.ish = a.isw = 1;
+    a.y = y; a.Do = D; a.Ho = H; a.Wo = W; a.ldy = ldy; a.Nc = Nc; a.osd = a.osh = a.osw = 1;
+    a.w = w; a.wT = wT;
+    a.ntaps = 1;
+    return a;
+}
+// dW[K x Nc] += X[M x K]^T * dY[M x Nc]  on the weight-gradient kernel (dW must be zero before)
+WgradArgs gemm_tn(int D, int H, int W, const float* x, int ldx, int K, const float* dy, int ldy, int Nc, float* dw) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.N = 1; a.Di = D; a.Hi = H; a.Wi = W; a.ldx = ldx; a.K = K;
+    a.Gd = D; a.Gh = H; a.Gw = W; a.isd = a.ish = a.isw = 1;
+    a.dy = dy; a.ldy = ldy; a.Nc = Nc; a.dw = dw; a.ksplit = 1;
+    a.ntaps = 1;
+    return a;
+}
+
 void zero_strided(const Ctx& c, float* p, int ld, int64_t rows, int C) {
     if (c.dry) {
         if (ld == C) c.dry->push_back({p, (size_t)rows * C * sizeof(float)});      // dense buffers may move into the arena
@@ -1246,13 +1270,148 @@ struct p3d_handle {
         head(zr, kp, bp, /*with_sigmoid=*/false);
     }
 
+    // ---- self attention, utils/network.py:157-192 (mode 'bn', sub_size 2) --------------------------------------
+    struct AttnParams { Param *wf, *bf, *wg, *bg, *wh, *bh, *wo, *bo, *gamma; BN* bn; int ch; std::string name; };
+    // variables in the reference's creation order: name/conv3d{,_1,_2}, an unnamed top-level conv3d, an unnamed
+    // batch_normalization, then the top-level scalar 'gamma'+name (initialised to 0)
+    AttnParams attn_declare(const std::string& name, int ch) {
+        AttnParams a;
+        a.name = name; a.ch = ch;
+        const int ci = std::max(1, ch / 8);
+        if (ci % 4) throw P3dError("attention needs channel counts that are multiples of 32 (base multiple of 16)");
+        a.wf = conv_weight(name + "/conv3d/kernel", {1, 1, 1, ch, ci});   a.bf = add_param(name + "/conv3d/bias", {ci}, true, INIT_ZEROS);
+        a.wg = conv_weight(name + "/conv3d_1/kernel", {1, 1, 1, ch, ci}); a.bg = add_param(name + "/conv3d_1/bias", {ci}, true, INIT_ZEROS);
+        a.wh = conv_weight(name + "/conv3d_2/kernel", {1, 1, 1, ch, ch}); a.bh = add_param(name + "/conv3d_2/bias", {ch}, true, INIT_ZEROS);
+        const std::string oc = unique("conv3d");
+        a.wo = conv_weight(oc + "/kernel", {1, 1, 1, ch, ch}); a.bo = add_param(oc + "/bias", {ch}, true, INIT_ZEROS);
+        a.bn = add_bn("", ch, true);
+        a.gamma = add_param("gamma" + name, {1}, true, INIT_ZEROS);
+        return a;
+    }
+    // x -> relu(bn(conv(softmax(g f^T) h))) * gamma + x; with subsample the keys f and values h are max-pooled by 2
+    // (utils/network.py:178-181; the query pool has size sub_size/2 = 1).  `dropout` folds the tf.layers.dropout
+    // that follows the last block (p3d.py:388) into the mixing pass.
+    Act* attn_run(const AttnParams& ap, Act* x, bool subsample, const std::string& out_name, bool dropout = false) {
+        const int one[3] = {1, 1, 1}, two[3] = {2, 2, 2};
+        const int ch = ap.ch, ci = ch / 8, B = x->N;
+        if (x->C != ch) throw P3dError("attention declared for another channel count");
+        const std::string& nm = ap.name;
+        Act* f = conv(nm + "/f", x, ap.wf, ap.bf, one, one, ci, nullptr, "");
+        Act* gq = conv(nm + "/g", x, ap.wg, ap.bg, one, one, ci, nullptr, "");
+        Act* h = conv(nm + "/h", x, ap.wh, ap.bh, one, one, ch, nullptr, "");
+        if (subsample) {
+            if ((x->D | x->H | x->W) & 1) throw P3dError("attention sub-sampling needs even extents ('valid' pooling)");
+            f = maxpool(nm + "/pool_f", f, two, two, nullptr, "");
+            h = maxpool(nm + "/pool_h", h, two, two, nullptr, "");
+        }
+        const int Ng = gq->D * gq->H * gq->W, Nf = f->D * f->H * f->W, Nfp = (Nf + 3) / 4 * 4;
+        const bool pad = Nfp != Nf;
+        Act* o = new_act(nm + "/o", B, x->D, x->H, x->W, ch);
+        float* sbuf = dalloc<float>((int64_t)B * Ng * Nfp);       // scores, then the attention map beta (kept for backward)
+        float* dsbuf = dalloc<float>((int64_t)B * Ng * Nfp);      // d beta, then d scores
+        float *fpad = nullptr, *hpad = nullptr, *dfpad = nullptr, *dhpad = nullptr;
+        if (pad) {
+            fpad = dalloc<float>((int64_t)B * Nfp * ci); hpad = dalloc<float>((int64_t)B * Nfp * ch);
+            dfpad = dalloc<float>((int64_t)B * Nfp * ci); dhpad = dalloc<float>((int64_t)B * Nfp * ch);
+        }
+        char* flg = consume(gq); char* flf = consume(f); char* flh = consume(h);
+        {
+            Op op;
+            op.name = nm + "/core"; op.kind = "attention";
+            op.flops = 2.0 * B * (double)Ng * Nf * (ci + ch);
+            op.bytes = 4.0 * B * ((double)Ng * Nfp * 4 + (double)Ng * (ci + ch) + (double)Nf * (ci + ch));
+            op.bflops = 2 * op.flops; op.bbytes = 2 * op.bytes;
+            const int gD = gq->D, gH = gq->H, gW = gq->W;
+            // one GEMM per clip; if the planner slices K (few rows), the whole output is zeroed once and the launches add
+            auto gemm_each = [=](const Ctx& c, float* out, int ldo, int Nc, std::function<IgemmArgs(int)> mk) {
+                IgemmArgs t = mk(0);
+                const bool split = p3d_igemm2_plan(t, 1).splits > 1;
+                if (split) zero_strided(c, out, ldo, (int64_t)B * Ng, Nc);
+                for (int b = 0; b < B; ++b) launch_igemm(c, mk(b), split ? 1 : 0);
+            };
+            op.fwd = [=](const Ctx& c) {
+                const float* F = f->p; const float* H = h->p;
+                if (pad) {
+                    launch(c, "pad_rows_kernel", 0, 8.0 * B * Nfp * ci, [&]() { return p3d_pad_rows(f->p, fpad, B, Nf, Nfp, ci, c.s); });
+                    launch(c, "pad_rows_kernel", 0, 8.0 * B * Nfp * ch, [&]() { return p3d_pad_rows(h->p, hpad, B, Nf, Nfp, ch, c.s); });
+                    F = fpad; H = hpad;
+                }
+                gemm_each(c, sbuf, Nfp, Nfp, [=](int b) {
+                    return gemm_rows(gD, gH, gW, gq->p + (int64_t)b * Ng * gq->ld, gq->ld, ci, F + (int64_t)b * Nfp * ci, 1,
+                                     sbuf + (int64_t)b * Ng * Nfp, Nfp, Nfp);
+                });
+                launch(c, "softmax_fwd_kernel", 0, 8.0 * B * Ng * Nfp, [&]() { return p3d_softmax_rows(sbuf, (long long)B * Ng, Nf, Nfp, c.s); });
+                gemm_each(c, o->p, o->ld, ch, [=](int b) {
+                    return gemm_rows(gD, gH, gW, sbuf + (int64_t)b * Ng * Nfp, Nfp, Nfp, H + (int64_t)b * Nfp * ch, 0,
+                                     o->p + (int64_t)b * Ng * o->ld, o->ld, ch);
+                });
+            };
+            op.bwd = [=](const Ctx& c) {
+                if (*flg || *flf || *flh) throw P3dError("attention operands have one consumer each");
+                const float* F = pad ? fpad : f->p; const float* H = pad ? hpad : h->p;
+                float* dF = pad ? dfpad : f->g; float* dH = pad ? dhpad : h->g;
+                gemm_each(c, dsbuf, Nfp, Nfp, [=](int b) {          // d beta = d o * h^T
+                    return gemm_rows(gD, gH, gW, o->g + (int64_t)b * Ng * o->ld, o->ld, ch, H + (int64_t)b * Nfp * ch, 1,
+                                     dsbuf + (int64_t)b * Ng * Nfp, Nfp, Nfp);
+                });
+                zero_strided(c, dH, ch, (int64_t)B * Nfp, ch);
+                for (int b = 0; b < B; ++b)                        // d h = beta^T * d o
+                    launch_wgrad(c, gemm_tn(gD, gH, gW, sbuf + (int64_t)b * Ng * Nfp, Nfp, Nfp, o->g + (int64_t)b * Ng * o->ld, o->ld, ch,
+                                            dH + (int64_t)b * Nfp * ch));
+                launch(c, "softmax_bwd_kernel", 0, 12.0 * B * Ng * Nfp, [&]() { return p3d_softmax_rows_bwd(sbuf, dsbuf, (long long)B * Ng, Nf, Nfp, c.s); });
+                gemm_each(c, gq->g, gq->ld, ci, [=](int b) {        // d g = d s * f
+                    return gemm_rows(gD, gH, gW, dsbuf + (int64_t)b * Ng * Nfp, Nfp, Nfp, F + (int64_t)b * Nfp * ci, 0,
+                                     gq->g + (int64_t)b * Ng * gq->ld, gq->ld, ci);
+                });
+                zero_strided(c, dF, ci, (int64_t)B * Nfp, ci);
+                for (int b = 0; b < B; ++b)                        // d f = d s^T * g
+                    launch_wgrad(c, gemm_tn(gD, gH, gW, dsbuf + (int64_t)b * Ng * Nfp, Nfp, Nfp, gq->p + (int64_t)b * Ng * gq->ld, gq->ld, ci,
+                                            dF + (int64_t)b * Nfp * ci));
+                if (pad) {
+                    launch(c, "unpad_rows_kernel", 0, 8.0 * B * Nf * ci, [&]() { return p3d_unpad_rows(dfpad, f->g, B, Nf, Nfp, ci, c.s); });
+                    launch(c, "unpad_rows_kernel", 0, 8.0 * B * Nf * ch, [&]() { return p3d_unpad_rows(dhpad, h->g, B, Nf, Nfp, ch, c.s); });
+                }
+            };
+            ops.push_back(op);
+        }
+        Act* y = conv(nm + "/out", o, ap.wo, ap.bo, one, one, ch, ap.bn, "");
+        Act* r = bn_apply(nm + "/out_bn", 0, y, ap.bn, nullptr, nullptr, nullptr, "");
+        Act* z = new_act(out_name, B, x->D, x->H, x->W, ch);
+        char* flr = consume(r); char* flx = consume(x);
+        {
+            Op op;
+            op.name = nm + "/mix"; op.kind = "attention_mix";
+            op.bytes = 4.0 * 3 * x->rows() * ch; op.bbytes = 4.0 * 5 * x->rows() * ch;
+            op.owns = {ap.gamma};
+            Param* gamma = ap.gamma;
+            auto mk = [=](const Ctx& c) {
+                AttnMixArgs a;
+                memset(&a, 0, sizeof(a));
+                a.M = x->rows(); a.C = ch; a.r = r->p; a.ldr = r->ld; a.x = x->p; a.ldx = x->ld; a.gamma = gamma->p;
+                a.z = z->p; a.ldz = z->ld; a.dz = z->g; a.dr = r->g; a.dx = x->g; a.accx = *flx; a.dgamma = gamma->g;
+                if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
+                return a;
+            };
+            const double fb = op.bytes, bb = op.bbytes;
+            op.fwd = [=](const Ctx& c) { launch(c, "mix_fwd_kernel", 0, fb, [&]() { return p3d_attn_mix_fwd(mk(c), c.s); }); };
+            op.bwd = [=](const Ctx& c) {
+                if (*flr) throw P3dError("attention branch has one consumer");
+                launch(c, "mix_bwd_kernel", 0, bb, [&]() { return p3d_attn_mix_bwd(mk(c), c.s); });
+            };
+            ops.push_back(op);
+        }
+        return z;
+    }
+
     // p3d_unetplusplus_nonsa (p3d.py:401-459): the nested UNet++ head without the attention blocks.  Every layer
     // is utils/network.py:100-110: named tf.layers.conv3d / conv3d_transpose + an UNNAMED batch_normalization
     // (it follows `training` and continues the backbone's counter in the reference's call order) + ReLU.
     // Variables are therefore created in the reference's order, but the ops run in an order in which each
     // concat buffer's whole consumer (the x_i_j conv) comes after every consumer of one of its slices -- see
     // consume().  Concats are zero-copy: producers write channel slices of the buffers below.
-    void build_unetpp_nonsa() {
+    // with sa = true: p3d_unetplusplus_ds (p3d.py:340-397), the same head with attention() on x_4_0, x_3_1, x_2_2
+    // and (keys / values pooled by 2, followed by the dropout) x_1_3
+    void build_unetpp(bool sa) {
         const int B = cfg.batch, T = cfg.frames, H = cfg.height, W = cfg.width, b = cfg.base;
         const int s111[3] = {1, 1, 1}, s222[3] = {2, 2, 2}, k211[3] = {2, 1, 1}, s211[3] = {2, 1, 1};
         Act* cat31 = new_act("cat_x_3_1", B, T / 8, H / 8, W / 8, 16 * b);    // [x_3_0 | upx_4_0]
@@ -1276,37 +1435,46 @@ struct p3d_handle {
             l.bn = add_bn("", filters, true);
             L[name] = l;
         };
-        // reference creation order (p3d.py:435-451)
+        // reference creation order (p3d.py:371-387 / 435-451)
+        AttnParams sa40, sa31, sa22, sa13;
+        if (sa) sa40 = attn_declare("x_4_0_sa", 16 * b);
         declare("upx_4_0", true, 16 * b, 8 * b, 1);
         declare("x_3_1", false, 16 * b, 8 * b, 2);
+        if (sa) sa31 = attn_declare("x_3_1_sa", 8 * b);
         declare("upx_3_0", true, 8 * b, 4 * b, 2);
         declare("x_2_1", false, 8 * b, 4 * b, 3);
         declare("upx_3_1", true, 8 * b, 4 * b, 2);
         declare("x_2_2", false, 8 * b, 4 * b, 3);
+        if (sa) sa22 = attn_declare("x_2_2_sa", 4 * b);
         declare("upx_2_0", true, 4 * b, 2 * b, 3);
         declare("x_1_1", false, 3 * b, 2 * b, 3);
         declare("upx_2_1", true, 4 * b, 2 * b, 3);
         declare("x_1_2", false, 4 * b, 2 * b, 3);
         declare("upx_2_2", true, 4 * b, 2 * b, 3);
         declare("x_1_3", false, 4 * b, 2 * b, 3);
+        if (sa) sa13 = attn_declare("x_1_3_sa", 2 * b);
         auto run = [&](const char* name, Act* x, Act* out, bool dropout = false) -> Act* {
             const Layer& l = L.at(name);
             Act* y = l.up ? deconv(name, x, l.k, l.bias, l.kk, s222, l.filters, l.bn, "", dropout)
                           : conv(name, x, l.k, l.bias, l.kk, s111, l.filters, l.bn, "", false, dropout);
             return bn_apply(std::string(name) + "_bn", 0, y, l.bn, nullptr, nullptr, out, name, dropout);
         };
+        if (sa) x_4_0 = attn_run(sa40, x_4_0, false, "x_4_0_sa");
         run("upx_4_0", x_4_0, new_view(cat31, 8 * b, 8 * b, ""));
         run("upx_3_0", x_3_0, new_view(cat21, 4 * b, 4 * b, ""));
         run("upx_2_0", x_2_0, new_view(cat11, b, 2 * b, ""));
         Act* x_3_1 = run("x_3_1", cat31, nullptr);
+        if (sa) x_3_1 = attn_run(sa31, x_3_1, false, "x_3_1_sa");
         Act* x_2_1 = run("x_2_1", cat21, new_view(cat22, 0, 4 * b, ""));
         run("x_1_1", cat11, new_view(cat12, 0, 2 * b, ""));
         run("upx_3_1", x_3_1, new_view(cat22, 4 * b, 4 * b, ""));
         run("upx_2_1", x_2_1, new_view(cat12, 2 * b, 2 * b, ""));
         Act* x_2_2 = run("x_2_2", cat22, nullptr);
+        if (sa) x_2_2 = attn_run(sa22, x_2_2, false, "x_2_2_sa");
         run("x_1_2", cat12, new_view(cat13, 0, 2 * b, ""));
         run("upx_2_2", x_2_2, new_view(cat13, 2 * b, 2 * b, ""));
-        Act* x_1_3 = run("x_1_3", cat13, nullptr, /*dropout=*/true);
+        Act* x_1_3 = run("x_1_3", cat13, nullptr, /*dropout=*/!sa);
+        if (sa) x_1_3 = attn_run(sa13, x_1_3, true, "x_1_3_sa", /*dropout=*/true);
         Param* kh = conv_weight("x_0_1/kernel", {3, 3, 3, 1, 2 * b});
         Param* bh = add_param("x_0_1/bias", {1}, true, INIT_ZEROS);
         head(x_1_3, kh, bh);
@@ -1612,14 +1780,15 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         HIPCHECK(hipEventCreateWithFlags(&h->ev_side_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_comm_done, hipEventDisableTiming));
-        if (cfg->structure < P3D_STRUCTURE_UNET || cfg->structure > P3D_STRUCTURE_GN_P3D_CONCAT) throw P3dError("unknown structure");
+        if (cfg->structure < P3D_STRUCTURE_UNET || cfg->structure > P3D_STRUCTURE_UNETPP_DS) throw P3dError("unknown structure");
         if (cfg->batch < 1) throw P3dError("batch must be >= 1");
         for (int i = 0; i < 3; ++i)
             if (cfg->blocks[i] < 1) throw P3dError("blocks must be >= 1");
         if (cfg->structure == P3D_STRUCTURE_CONCAT) h->build_concat();
         else if (cfg->structure == P3D_STRUCTURE_GN_P3D) h->build_gn_p3d(16);
         else if (cfg->structure == P3D_STRUCTURE_GN_P3D_CONCAT) h->build_gn_p3d(8);
-        else if (cfg->structure == P3D_STRUCTURE_UNETPP_NONSA) h->build_unetpp_nonsa();
+        else if (cfg->structure == P3D_STRUCTURE_UNETPP_NONSA) h->build_unetpp(false);
+        else if (cfg->structure == P3D_STRUCTURE_UNETPP_DS) h->build_unetpp(true);
         else if (cfg->structure == P3D_STRUCTURE_GN_P3D_DECODER) h->build_gn_decoder();
         else h->build_unet();
         h->finalize_build();

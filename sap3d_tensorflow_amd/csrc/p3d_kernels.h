@@ -219,6 +219,24 @@ struct CbamArgs {
 hipError_t p3d_cbam_forward(const CbamArgs& a, hipStream_t s);
 hipError_t p3d_cbam_backward(const CbamArgs& a, hipStream_t s);
 
+// ---- self attention (attention.hip; reference utils/network.py:157-192) -----------------------------------
+hipError_t p3d_softmax_rows(float* s, long long rows, int cols, int ld, hipStream_t st);          // in place; columns [cols, ld) := 0
+hipError_t p3d_softmax_rows_bwd(const float* beta, float* d, long long rows, int cols, int ld, hipStream_t st);   // d := ds, in place
+struct AttnMixArgs {                 // z = r * gamma + x  (utils/network.py:191), optional dropout on z (p3d.py:388)
+    long long M; int C;
+    const float* r; int ldr;         // relu(bn(conv(o)))
+    const float* x; int ldx;         // the block's input
+    const float* gamma;              // [1]
+    float* z; int ldz;
+    float drop_scale; float drop_rate; unsigned long long seed;
+    // backward
+    const float* dz; float* dr; float* dx; int accx; float* dgamma;
+};
+hipError_t p3d_attn_mix_fwd(const AttnMixArgs& a, hipStream_t s);
+hipError_t p3d_attn_mix_bwd(const AttnMixArgs& a, hipStream_t s);
+hipError_t p3d_pad_rows(const float* src, float* dst, int B, int N, int Npad, int C, hipStream_t s);     // [B][N][C] -> [B][Npad][C], zero tail
+hipError_t p3d_unpad_rows(const float* src, float* dst, int B, int N, int Npad, int C, hipStream_t s);   // the reverse (tail dropped)
+
 // ---- max pool (tf.nn.max_pool3d SAME; p3d.py:177,183,189,195) ---------------------------------
 struct PoolArgs {
     const float* x; int N, Di, Hi, Wi, C, ldx;

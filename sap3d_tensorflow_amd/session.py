@@ -10,7 +10,8 @@ from ._lib import P3dConfig, P3dError, P3dOpTime, check, fptr, lib
 STRUCTURES = {"unet": 0, "concat": 1, "gn_p3d": 2,     # train.py:149-154 --structure
               "unet++nonsa": 3,                          # p3d.py:401 p3d_unetplusplus_nonsa
               "gn_p3d_decoder": 4,                       # gn/p3d_gn.py:489 inference_p3d_decoder_block (net='P3D_DECODER')
-              "gn_p3d_concat": 5}                        # gn/p3d_gn.py:279 inference_p3d_concat (net='P3D_CONCAT')
+              "gn_p3d_concat": 5,                        # gn/p3d_gn.py:279 inference_p3d_concat (net='P3D_CONCAT')
+              "unet++ds": 6}                             # p3d.py:340 p3d_unetplusplus_ds (unet++ with self attention)
 
 
 class P3DSession:

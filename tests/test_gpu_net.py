@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 def randomise_norm_params(params, seed=5):
     rng = np.random.default_rng(seed)
     for k, v in params.items():
-        if k.endswith('gamma'):
+        if k.startswith('gamma'):           # attention mixing scalars (init 0 would switch their branch's gradients off)
+            v[:] = rng.uniform(0.4, 1.0, v.shape)
+        elif k.endswith('gamma'):
             v[:] = rng.uniform(0.5, 1.5, v.shape)
         elif k.endswith('beta'):
             v[:] = rng.uniform(-0.3, 0.3, v.shape)
@@ -243,6 +245,69 @@ def test_unetplusplus_nonsa_dropout_and_train_steps():
     for n in p64:
         if n.endswith(('moving_mean', 'moving_variance')):
             assert np.allclose(s.get_param(n), p64[n], rtol=1e-2, atol=2e-3), n
+    s.close()
+
+
+DS_CASES = [
+    (p3d.NetConfig(base=16, blocks=(1, 1, 2)), (2, 16, 32, 32)),     # x_4_0: 1x2x2 = 4 positions
+    (p3d.NetConfig(base=16, blocks=(1, 2, 1)), (1, 16, 48, 32)),     # x_4_0: 1x3x2 = 6 positions -> key/value rows padded to 8
+]
+
+
+@pytest.mark.parametrize("cfg,shape", DS_CASES)
+def test_unetplusplus_ds_self_attention(cfg, shape):
+    """p3d.p3d_unetplusplus_ds (p3d.py:340-397): the UNet++ head with attention() (utils/network.py:157-192) after
+    x_4_0, x_3_1, x_2_2 (full) and x_1_3 (keys / values max-pooled by 2, then dropout).  The mixing scalars are
+    randomised (their TF initial value 0 would switch the attention gradients off)."""
+    st = 'unet++ds'
+    p64 = randomise_norm_params(p3d.init_params(1, st, cfg, dtype=np.float64))
+    assert abs(float(p64['gammax_2_2_sa'][0])) > 0.3
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    x = p3d.synthetic_clip(0, shape + (3,))
+    y = p3d.synthetic_target(3, shape)
+    s = make_session(cfg, shape, p32, st)
+    assert [n for n, _, _ in s.variables()] == list(p64)
+    for training in (False, True):
+        want, g = p3d.forward(p64, x.astype(np.float64), 0.0, training, st, cfg, np.float64)
+        got = s.forward(x, 0.0, training)
+        for tap in ['x_4_0_sa', 'x_3_1', 'x_3_1_sa', 'x_2_2_sa', 'x_1_3', 'x_1_3_sa']:
+            w = g.tape.taps[tap].data
+            a = s.activation(tap)
+            assert a.shape == w.shape, tap
+            # scores of O(10) go through exp(): an fp32 rounding of s shows up e^|s|-fold conditioned in beta, so the
+            # attention outputs get 3e-4 where plain conv / BN taps get 1e-4
+            assert np.abs(a - w).max() <= (3e-4 if tap.endswith('_sa') else 1e-4) * max(np.abs(w).max(), 1.0), (tap, training)
+        assert np.abs(got - want).max() < 1e-4, training
+    # gradients without dropout.  + 1.5e-2: a deterministic ReLU sign flip next to batch_normalization_33 moves every
+    # upstream gradient by 0.2-0.4 % (0.7 % on the first block's f / g kernels, which are differences of softmax
+    # terms); downstream of it the HIP path and the fp32 oracle have the same error to 3 digits (tools/ds_probe.py)
+    l64, pr64, g64, _ = p3d.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True, st, cfg, np.float64)
+    _, _, g32, _ = p3d.loss_and_grads(dict(p32), x, y, 0.0, True, st, cfg, np.float32)
+    loss, pred = s.backward(x, y, 0.0)
+    assert abs(loss - l64) < 1e-5 * abs(l64)
+    assert np.abs(pred - pr64).max() < 1e-4
+    scale = np.median([np.linalg.norm(g) for g in g64.values()])
+    floor = 1e-2 * scale
+    for n, want in g64.items():
+        assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3 + 1.5e-2, n
+    # dropout 0.5 sits on the output of the last attention block (p3d.py:388): read the keep pattern back.  Dropping
+    # half of the head's inputs doubles the weight of a flipped element, hence the wider gradient allowance.
+    s.forward(x, 0.0, True)
+    base = s.activation('x_1_3_sa')
+    s.backward(x, y, dropout=0.5, seed=11)
+    dropped = s.activation('x_1_3_sa')
+    keep = np.where(base != 0, dropped != 0, True)
+    assert 0.45 < keep[base != 0].mean() < 0.55
+    l64, pr64, g64, _ = p3d.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.5, True, st, cfg, np.float64,
+                                           keep_mask=keep.astype(np.float64))
+    _, _, g32, _ = p3d.loss_and_grads(dict(p32), x, y, 0.5, True, st, cfg, np.float32, keep_mask=keep.astype(np.float32))
+    loss, pred = s.backward(x, y, dropout=0.5, seed=11)
+    assert abs(loss - l64) < 1e-5 * abs(l64)
+    assert np.abs(pred - pr64).max() < 1e-4
+    scale = np.median([np.linalg.norm(g) for g in g64.values()])
+    floor = 1e-2 * scale
+    for n, want in g64.items():
+        assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3 + 5e-2, n
     s.close()
 
 

@@ -13,7 +13,9 @@ import torch_ref
 def _randomise_norm_params(params, seed=5):
     rng = np.random.default_rng(seed)
     for k, v in params.items():
-        if k.endswith('gamma'):
+        if k.startswith('gamma'):           # attention mixing scalars (init 0 would switch their branch's gradients off)
+            v[:] = rng.uniform(0.4, 1.0, v.shape)
+        elif k.endswith('gamma'):
             v[:] = rng.uniform(0.5, 1.5, v.shape)
         elif k.endswith('beta'):
             v[:] = rng.uniform(-0.3, 0.3, v.shape)
@@ -30,10 +32,10 @@ def rel_l2(a, b, floor):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), floor)
 
 
-TORCH_METHOD = {"unet": "unet", "concat": "concat", "unet++nonsa": "unetpp_nonsa"}
+TORCH_METHOD = {"unet": "unet", "concat": "concat", "unet++nonsa": "unetpp_nonsa", "unet++ds": "unetpp_ds"}
 
 
-@pytest.mark.parametrize("structure", ["unet", "concat", "unet++nonsa"])
+@pytest.mark.parametrize("structure", ["unet", "concat", "unet++nonsa", "unet++ds"])
 @pytest.mark.parametrize("training", [True, False])
 def test_small_net_fp64(structure, training):
     cfg = p3d.NetConfig(base=8, blocks=(3, 3, 3))

@@ -198,6 +198,61 @@ def _unetpp_nonsa(self, x_ndhwc, training):
 TorchP3D.unetpp_nonsa = _unetpp_nonsa
 
 
+def _attention(self, x, name, training, subsample=False, sub_size=2):
+    """utils/network.py:157-192 on NCDHW tensors."""
+    p = self.p
+    B, ch = x.shape[0], x.shape[1]
+    c1 = lambda t, n: conv3d_same(t, p[n + '/kernel'], (1, 1, 1), p[n + '/bias'])
+    f, g, h = c1(x, name + '/conv3d'), c1(x, name + '/conv3d_1'), c1(x, name + '/conv3d_2')
+    if subsample:
+        f = F.max_pool3d(f, sub_size, sub_size)
+        if sub_size // 2 > 1:
+            g = F.max_pool3d(g, sub_size // 2, sub_size // 2)
+        h = F.max_pool3d(h, sub_size, sub_size)
+    flat = lambda t: t.permute(0, 2, 3, 4, 1).reshape(B, -1, t.shape[1])        # [B, positions, channels]
+    beta = torch.softmax(flat(g) @ flat(f).transpose(1, 2), dim=-1)
+    o = beta @ flat(h)
+    D, H, W = (e * 2 // sub_size for e in x.shape[2:])
+    o = o.reshape(B, D, H, W, ch).permute(0, 4, 1, 2, 3)
+    o = c1(o, self.uniq('conv3d'))
+    o = torch.relu(self.bn(o, training))
+    return o * p['gamma' + name] + x
+
+
+def _unetpp_ds(self, x_ndhwc, training):
+    """p3d.py:340-397."""
+    p = self.p
+    x = x_ndhwc.permute(0, 4, 1, 2, 3)
+    x_2_0, x_3_0, x_4_0 = self.encoder(x, training)
+    x_1_0 = max_pool_same(self.stem, (2, 1, 1), (2, 1, 1))
+
+    def up(t, name, s=(2, 2, 2)):
+        y = conv3d_transpose_same(t, p[name + '/kernel'], s, p[name + '/bias'])
+        return torch.relu(self.bn(y, training))
+
+    def conv(ts, name):
+        y = conv3d_same(torch.cat(ts, 1), p[name + '/kernel'], (1, 1, 1), p[name + '/bias'])
+        return torch.relu(self.bn(y, training))
+    x_4_0 = _attention(self, x_4_0, 'x_4_0_sa', training)
+    upx_4_0 = up(x_4_0, 'upx_4_0')
+    x_3_1 = _attention(self, conv([x_3_0, upx_4_0], 'x_3_1'), 'x_3_1_sa', training)
+    upx_3_0 = up(x_3_0, 'upx_3_0')
+    x_2_1 = conv([x_2_0, upx_3_0], 'x_2_1')
+    upx_3_1 = up(x_3_1, 'upx_3_1')
+    x_2_2 = _attention(self, conv([x_2_1, upx_3_1], 'x_2_2'), 'x_2_2_sa', training)
+    upx_2_0 = up(x_2_0, 'upx_2_0')
+    x_1_1 = conv([x_1_0, upx_2_0], 'x_1_1')
+    upx_2_1 = up(x_2_1, 'upx_2_1')
+    x_1_2 = conv([x_1_1, upx_2_1], 'x_1_2')
+    upx_2_2 = up(x_2_2, 'upx_2_2')
+    x_1_3 = _attention(self, conv([x_1_2, upx_2_2], 'x_1_3'), 'x_1_3_sa', training, subsample=True)
+    d = conv3d_transpose_same(x_1_3, p['x_0_1/kernel'], (2, 2, 2), p['x_0_1/bias'])
+    return torch.sigmoid(d).permute(0, 2, 3, 4, 1)
+
+
+TorchP3D.unetpp_ds = _unetpp_ds
+
+
 def smooth_l1_sum(pred, y):
     d = pred - y
     ad = d.abs()
