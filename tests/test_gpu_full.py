@@ -93,3 +93,64 @@ def test_config2_forward_backward(ref_params):
     for n in e_hip:
         assert e_hip[n] <= 2.5 * e_o32[n] + 2e-2, (n, e_hip[n], e_o32[n])
     s.close()
+
+
+@pytest.mark.parametrize("structure,shape,step,tol", [
+    ("unet", (8, 16, 112, 112), 2e-5, 8e-2),          # BASELINE.json configs[2]: batch 8, 16x112x112
+    ("unet", (1, 32, 224, 224), 2e-5, 8e-2),          # the clip shape of configs[4] (32 frames of 224x224), one clip
+    ("gn_p3d", (2, 16, 112, 112), 1e-5, 15e-2),       # configs[3] graph (GroupNorm + CBAM): CBAM's arg-max routing
+])                                                    # bends the loss sooner (10 % off at 2e-5 L), so half the step
+def test_directional_derivative_at_full_size(structure, shape, step, tol):
+    """Size-independent property, no oracle involved: moving the parameters by a small step delta must change the
+    loss by <g, delta>, g being the gradient the backward pass returned.  Checked at the reference architecture
+    (62 M parameters, 199 layers) and at BASELINE clip sizes where the numpy oracle would need hours, separately
+    for four parameter groups (stem + stage 1, stage 2, stage 3, head) with delta along the group's own gradient.
+    The step is tiny on purpose: at random initialisation the loss of this 199-layer ReLU/max-pool net is linear
+    along a backbone direction only while it moves by ~1e-4 of its value (tools/dd_probe.py: the predicted change
+    is met within 1.5 % at 2e-5 L and saturates beyond 3e-4 L; head directions stay linear 1000x further).  So
+    every group moves the loss by `step` = 1-2e-5 L (fp32 read-back of L resolves ~1e-7 L), central difference, and the
+    prediction uses the step each fp32 parameter actually took, most components being below one ulp."""
+    from sap3d_tensorflow_amd import P3DSession
+    from sap3d_tensorflow_amd import synthetic
+    import re
+    B, T, H, W = shape
+    s = P3DSession(structure, batch=B, frames=T, height=H, width=W, seed=3)
+    x = synthetic.synthetic_clip(0, (B, T, H, W, 3))
+    y = synthetic.synthetic_target(3, (B, T, H, W))
+    theta = s.save()
+    rng = np.random.default_rng(0)
+    for n in sorted(theta):                # move off the symmetric point beta = 0 (about half of every layer active)
+        if n.endswith('/beta'):
+            theta[n] = rng.uniform(-0.2, 0.2, theta[n].shape).astype(np.float32)
+    s.load(theta)
+    loss0, _ = s.backward(x, y, 0.0)
+    assert np.isfinite(loss0)
+    trainable = [n for n, _, t in s.variables() if t]
+    g = {n: s.get_grad(n).astype(np.float64) for n in trainable}
+    # variables are created in forward order: cut the list at the first variable of blocks 3 and 11 and of the head
+    order = {n: i for i, n in enumerate(trainable)}
+    def first(pattern):
+        return min(i for n, i in order.items() if re.search(pattern, n))
+    cuts = [0, first(r'conv3_3_1$'), first(r'conv3_11_1$'),
+            first(r'^(conv3d_transpose/kernel|deconv_pool3/kernel)$'), len(trainable)]
+    if structure == 'gn_p3d':              # deconv_pool3 is created before stage 3 there: head = everything after stage 3
+        cuts[3] = first(r'^deconv_pool4/kernel$')
+    groups = [trainable[cuts[k]:cuts[k + 1]] for k in range(4)]
+    assert all(len(grp) > 10 for grp in groups) and sum(len(grp) for grp in groups) == len(trainable)
+    for k, names in enumerate(groups):
+        gn = float(np.sqrt(sum((g[n] ** 2).sum() for n in names)))
+        assert np.isfinite(gn) and gn > 0, k
+        eps = step * abs(loss0) / gn
+        losses, moved = [], []
+        for sign in (+1.0, -1.0):
+            m = dict(theta)
+            for n in names:
+                m[n] = (theta[n].astype(np.float64) + sign * eps * g[n] / gn).astype(np.float32)
+            s.load(m)
+            losses.append(s.backward(x, y, 0.0)[0])
+            moved.append(m)
+        predicted = sum(float((g[n] * (moved[0][n].astype(np.float64) - moved[1][n].astype(np.float64))).sum()) for n in names)
+        measured = losses[0] - losses[1]
+        assert predicted > 0.5 * step * abs(loss0), (k, predicted)
+        assert abs(measured - predicted) <= tol * abs(predicted), (k, measured, predicted, loss0, eps, gn)
+    s.close()
