@@ -99,6 +99,12 @@ int p3d_train_step(p3d_handle* h, const float* x, const float* y, float dropout_
 int p3d_backward(p3d_handle* h, const float* x, const float* y, float dropout_rate, uint64_t seed,
                  float* loss, float* pred);
 
+/* BASELINE.json configs[4] ("fp16 MFMA pointwise convs"; no reference counterpart, the reference is fp32 throughout):
+ * when enabled, every 1x1x1 convolution (forward and input gradient) rounds its operands to fp16 in registers and
+ * multiplies on the fp16 matrix cores with fp32 accumulation.  Everything stored stays fp32.  Parity for this mode is
+ * fp16-level (2e-2 relative on the saliency maps); the default, fp32, is the mode the 1e-3 target applies to. */
+int p3d_set_pointwise_fp16(p3d_handle* h, int enable);
+
 /* tf.train.AdamOptimizer(lr, beta1, beta2, epsilon) (train.py:168; defaults 1e-4, .9, .999, 1e-8). */
 int p3d_set_adam(p3d_handle* h, float lr, float beta1, float beta2, float eps);
 

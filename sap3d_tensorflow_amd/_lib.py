@@ -43,6 +43,7 @@ SIGNATURES = {
     "p3d_init_params": (C.c_int, [C.c_void_p, C.c_uint64]),
     "p3d_forward": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_float, C.c_uint64, _fp]),
     "p3d_predict_windows": (C.c_int, [C.c_void_p, _fp, _fp]),
+    "p3d_set_pointwise_fp16": (C.c_int, [C.c_void_p, C.c_int]),
     "p3d_train_step": (C.c_int, [C.c_void_p, _fp, _fp, C.c_float, C.c_uint64, _fp]),
     "p3d_backward": (C.c_int, [C.c_void_p, _fp, _fp, C.c_float, C.c_uint64, _fp, _fp]),
     "p3d_set_adam": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]),

@@ -151,7 +151,13 @@ __device__ __forceinline__ void issue_stage(const IgemmArgs& p, float* __restric
     if (++st.kc == kchunks) { st.kc = 0; ++st.t; }
 }
 
-template <int BM, int BN, bool WT>
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x4 to_half4(float4 v) { f16x4 r = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; return r; }
+
+// F16: the pointwise-conv option of BASELINE configs[4] -- operands stay fp32 in HBM and LDS, the fragments are
+// rounded to fp16 in registers and one v_mfma_f32_32x32x8_f16 (fp32 accumulate) replaces four fp32 MFMAs: a lane's
+// float4 fragment holds k = 8c + 4h + {0..3}, which is exactly the A / B operand layout of that instruction.
+template <int BM, int BN, bool WT, bool F16>
 __device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, const float* __restrict__ b_st,
                                               f32x16 (&acc)[BM / 64][BN / 64], int wm, int wn, int h, int l31) {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -179,6 +185,17 @@ __device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, co
 #ifdef P3D_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
+        if constexpr (F16) {
+            f16x4 ah[TM], bh[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ah[i] = to_half4(a[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bh[j] = to_half4(b[j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -190,6 +207,7 @@ __device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, co
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                 }
             }
+        }
 #ifdef P3D_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -198,7 +216,7 @@ __device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, co
 
 // One pipeline step with COMPILE-TIME stage addresses and restrict-qualified views of the ring.
 // Branch-free: wait for this step's loads, barrier, issue step+2, compute.
-template <int BM, int BN, bool WT>
+template <int BM, int BN, bool WT, bool F16>
 __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict__ a_dst, float* __restrict__ b_dst,
                                           const float* __restrict__ a_src, const float* __restrict__ b_src,
                                           f32x16 (&acc)[BM / 64][BN / 64], LoadState<BM / 32, BN / 32>& st, int nsteps,
@@ -208,7 +226,7 @@ __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict_
     wait_vmcnt<(Ring<BM, BN>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();      // ... and for every wave; everyone is also done reading the stage refilled next
     issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
-    compute_stage<BM, BN, WT>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
+    compute_stage<BM, BN, WT, F16>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
 }
 
 template <int BM, int BN, bool WT, int K>
@@ -223,7 +241,7 @@ struct PrologueLoop {
     }
 };
 
-template <int BM, int BN, bool WT, int K>
+template <int BM, int BN, bool WT, bool F16, int K>
 struct StepLoop {
     static __device__ __forceinline__ void run(const IgemmArgs& p, float* As, float* Bs, f32x16 (&acc)[BM / 64][BN / 64],
                                                LoadState<BM / 32, BN / 32>& st, int base, int nsteps, int kchunks, int wave,
@@ -232,15 +250,15 @@ struct StepLoop {
         if constexpr (K < STAGES) {
             if (base + K < nsteps) {
                 constexpr int D = (K + STAGES - 1) % STAGES;      // stage refilled while stage K is consumed
-                pipe_step<BM, BN, WT>(p, As + D * (BM * BK), Bs + D * (BK * BN), As + K * (BM * BK), Bs + K * (BK * BN), acc, st,
+                pipe_step<BM, BN, WT, F16>(p, As + D * (BM * BK), Bs + D * (BK * BN), As + K * (BM * BK), Bs + K * (BK * BN), acc, st,
                                       nsteps, kchunks, wave, lane, wm, wn);
             }
-            StepLoop<BM, BN, WT, K + 1>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn);
+            StepLoop<BM, BN, WT, F16, K + 1>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn);
         }
     }
 };
 
-template <int BM, int BN, bool WT>
+template <int BM, int BN, bool WT, bool F16 = false>
 __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int LA = BM / 32;                 // A glds per wave per step
@@ -302,7 +320,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     // that was consumed one step earlier.  All stage addresses are compile-time constants (StepLoop).
     PrologueLoop<BM, BN, WT, 0>::run(p, As, Bs, st, nsteps, kchunks, wave, lane);
     for (int base = 0; base < nsteps; base += STAGES)
-        StepLoop<BM, BN, WT, 0>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn);
+        StepLoop<BM, BN, WT, F16, 0>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn);
     __syncthreads();      // rowOut written above is read below (also when nsteps == 0)
 
     // ---- epilogue ----------------------------------------------------------------------------------
@@ -402,6 +420,17 @@ hipError_t launch_t(const IgemmArgs& a, int splits, hipStream_t s) {
         hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         attr_done = true;
+    }
+    if (a.f16) {
+        static bool attr16_done = false;
+        if (!attr16_done) {
+            hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            attr16_done = true;
+        }
+        if (a.wT) hipLaunchKernelGGL((igemm2_kernel<BM, BN, true, true>), grid, dim3(256), sm, s, a);
+        else      hipLaunchKernelGGL((igemm2_kernel<BM, BN, false, true>), grid, dim3(256), sm, s, a);
+        return hipGetLastError();
     }
     if (a.wT) hipLaunchKernelGGL((igemm2_kernel<BM, BN, true>), grid, dim3(256), sm, s, a);
     else      hipLaunchKernelGGL((igemm2_kernel<BM, BN, false>), grid, dim3(256), sm, s, a);

@@ -162,7 +162,9 @@ void launch_igemm(const Ctx& c, const IgemmArgs& a0, int allow_split = 0) {
     }
     a.zeros = g_zero_page;
     const P3dIgemmPlan pl = p3d_igemm2_plan(a, allow_split);
-    launch(c, pl.name, fl, by, [&]() { return p3d_launch_igemm2(a, pl, c.s); });
+    const char* name = pl.name;
+    if (a.f16) name = pl.bm == 128 ? (pl.bn == 128 ? "igemm2_kernel<128,128,f16>" : "igemm2_kernel<128,64,f16>") : "igemm2_kernel<64,64,f16>";
+    launch(c, name, fl, by, [&]() { return p3d_launch_igemm2(a, pl, c.s); });
 }
 
 void zero_strided(const Ctx& c, float* p, int ld, int64_t rows, int C);
@@ -478,6 +480,10 @@ struct p3d_handle {
         return k == 0 ? base : base + "_" + std::to_string(k);
     }
 
+    // BASELINE configs[4] option: 1x1x1 convolutions (forward and input gradient) round their operand fragments to
+    // fp16 in registers and run on the fp16 MFMA with fp32 accumulation; storage, weights, statistics, every other
+    // conv and all weight gradients stay fp32.  Off by default: the 1e-3 parity target is for the fp32 path.
+    bool pointwise_f16 = false;
     std::string var_prefix;      // enclosing tf.variable_scope ("P3D/" for gn/p3d_gn.py:490), part of every variable name
     Param* add_param(const std::string& bare_name, std::vector<int64_t> shape, bool trainable, int init) {
         const std::string name = var_prefix + bare_name;
@@ -596,6 +602,7 @@ struct p3d_handle {
         op.fwd = [=](const Ctx& c) {
             std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
                                                         nullptr, 0, stem)};
+            if (ntap == 1 && !stem && pointwise_f16) v[0].f16 = 1;
             BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
             run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? bn_stats(sbn) : nullptr);
         };
@@ -608,6 +615,7 @@ struct p3d_handle {
                 const int accum = *xflag;
                 auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, w->p, nullptr, nullptr, accum,
                                                /*include_empty=*/!accum);
+                if (ntap == 1 && !stem && pointwise_f16) for (auto& a : v) a.f16 = 1;
                 run_igemm_group(c, v, x->g, x->ld, x->rows(), Cin, accum != 0, nullptr);
             }
         };
@@ -1923,6 +1931,13 @@ int p3d_forward(p3d_handle* h, const float* x, int training, float dropout_rate,
     Ctx c; c.training = training != 0; c.drop = dropout_rate; c.seed = seed; c.update_moving = false; c.s = h->stream;
     h->run_forward(c);
     h->download_act(h->pred, pred);
+    API_END
+}
+
+int p3d_set_pointwise_fp16(p3d_handle* h, int enable) {
+    API_BEGIN
+    if (!h) throw P3dError("null handle");
+    h->pointwise_f16 = enable != 0;
     API_END
 }
 

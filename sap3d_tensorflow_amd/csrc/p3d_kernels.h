@@ -49,6 +49,7 @@ struct IgemmArgs {
     int stem_wpad;        // floats of left padding (pad_w*Cin)
     const float* zeros;   // >= 128 B of zeros in device memory (source for padded / tail lanes; igemm2 only)
     int exp;              // tuning experiments only (tools/tune_igemm.py): 1 skip main loop, 2 skip epilogue
+    int f16;              // 1: round the operand fragments to fp16 and use the fp16 MFMA (fp32 accumulate); pointwise convs of configs[4]
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
 };

@@ -118,6 +118,10 @@ class P3DSession:
         check(lib().p3d_forward(self._h, fptr(x), int(bool(training)), float(dropout), seed, fptr(pred)))
         return pred
 
+    def set_pointwise_fp16(self, enable=True):
+        """BASELINE configs[4]: 1x1x1 convs on the fp16 matrix cores (fp32 accumulate, fp32 storage); fp16-level parity."""
+        check(lib().p3d_set_pointwise_fp16(self._h, int(bool(enable))))
+
     def predict_windows(self, x):
         """B windows of gen_pred.py:100-168 at once: row k equals forward(x[k:k+1], training=False) of a batch-1
         session, i.e. every batch-statistics BN normalises each clip by its own statistics."""

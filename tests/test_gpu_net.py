@@ -513,3 +513,42 @@ def test_predict_windows_equals_batch_of_one_forwards():
     s1.close()
     # and it matters: a plain batched forward couples the windows through the batch statistics
     assert np.abs(coupled - batched).max() > 1e-3
+
+
+def test_pointwise_fp16_mode():
+    """BASELINE.json configs[4]: "fp16 MFMA pointwise convs".  p3d_set_pointwise_fp16 makes every 1x1x1 conv (forward
+    and input gradient) round its operands to fp16 in registers and accumulate in fp32; nothing stored changes.
+    Parity for this mode is fp16-level: saliency maps and loss within 2e-2 relative of the fp64 oracle (SURVEY.md
+    8d, cfg 5), gradients within 5e-2 rel-L2; and the switch must really change the arithmetic and be reversible."""
+    cfg, shape = SMALL[1]
+    p64 = randomise_norm_params(p3d.init_params(1, 'unet', cfg, dtype=np.float64))
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    x = p3d.synthetic_clip(0, shape + (3,))
+    y = p3d.synthetic_target(3, shape)
+    s = make_session(cfg, shape, p32)
+    full = s.forward(x, 0.0, True)
+    s.set_pointwise_fp16(True)
+    half = s.forward(x, 0.0, True)
+    want, _ = p3d.forward(p64, x.astype(np.float64), 0.0, True, 'unet', cfg, np.float64)
+    assert np.abs(full - want).max() < 1e-4
+    assert 1e-6 < np.abs(half - full).max()                      # the fp16 rounding is visible ...
+    assert np.abs(half - want).max() <= 2e-2 * np.abs(want).max()  # ... and fp16-sized
+    l64, pr64, g64, _ = p3d.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True, 'unet', cfg, np.float64)
+    loss, pred = s.backward(x, y, 0.0)
+    assert abs(loss - l64) <= 2e-2 * abs(l64)
+    # Gradients: the head's (between the last pointwise conv and the loss) are fp16-accurate.  Deeper ones are not
+    # comparable element by element at random initialisation: the 1e-3 forward perturbation flips ~1e-3 of all ReLU
+    # decisions, and the gradient of this net decorrelates under such flips layer by layer (30 % rel-L2 at the stem,
+    # see tools/dd_probe.py for how short the linear range is) -- there the direction must survive: cosine >= 0.8.
+    for n, w in g64.items():
+        got = s.get_grad(n).astype(np.float64)
+        assert np.isfinite(got).all(), n
+        if n.startswith(('conv3d/', 'conv3d_transpose_3/', 'deconv3_bn/')):      # deconv4_conv1, the output deconv, the BN before them
+            assert rel_l2(got, w, 1e-2 * np.linalg.norm(w)) <= 5e-2, n
+        elif np.linalg.norm(w) > 1e-6 * max(np.abs(l64), 1.0) and not n.endswith('bias'):
+            cos = float((got * w).sum() / (np.linalg.norm(got) * np.linalg.norm(w)))
+            assert cos >= 0.8, (n, cos)
+    s.set_pointwise_fp16(False)
+    again = s.forward(x, 0.0, True)
+    assert np.abs(again - full).max() < 1e-5
+    s.close()
