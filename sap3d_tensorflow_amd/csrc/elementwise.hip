@@ -587,3 +587,50 @@ hipError_t p3d_colsum(const float* dy, int ld, long M, int C, float* out, hipStr
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)bx, (C + 255) / 256), dim3(256), 0, s, dy, ld, (long long)M, C, out);
     return hipGetLastError();
 }
+
+// ---- stem (firstconv1, p3d.py:172: [1,7,7,3,64] stride [1,2,2]) on the pipelined kernels -----------------------
+// With 3 input channels a pixel is 12 bytes and nothing is 16-byte aligned.  The input is therefore re-laid with a
+// fourth, zero, channel and the SAME padding of the W axis written out: x4[row][pad_before + w][0..3], row = (n,d,h),
+// Wp = W + total W padding.  A kernel row kh then reads ONE contiguous, aligned run of kw*4 floats per output
+// position (start 2*wo pixels), i.e. the stem is a 7-tap convolution with K = 28 on the ordinary implicit-GEMM and
+// weight-gradient kernels; the weights are packed to [kh][kw*4 + ci][Cout] with zeros at ci = 3.
+namespace {
+__global__ __launch_bounds__(256) void stem_pad_kernel(const float* x, float* x4, long long rows, int W, int Wp, int pad) {
+    const long long total = rows * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / W;
+        const int w = (int)(i - r * W);
+        const float* src = x + i * 3;
+        *reinterpret_cast<float4*>(x4 + (r * Wp + pad + w) * 4) = make_float4(src[0], src[1], src[2], 0.f);
+    }
+}
+// w [kh][kw][3][Co] -> w4 [kh][kw*4 + ci][Co]
+__global__ __launch_bounds__(256) void stem_pack_w_kernel(const float* w, float* w4, int taps_hw, int Co) {
+    const int total = taps_hw * 4 * Co;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % Co, ci = (i / Co) & 3, t = i / (4 * Co);
+        w4[i] = ci < 3 ? w[(t * 3 + ci) * Co + co] : 0.f;
+    }
+}
+// dw [kh][kw][3][Co] += dw4 [kh][kw*4 + ci][Co]
+__global__ __launch_bounds__(256) void stem_unpack_dw_kernel(const float* dw4, float* dw, int taps_hw, int Co) {
+    const int total = taps_hw * 3 * Co;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % Co, ci = (i / Co) % 3, t = i / (3 * Co);
+        dw[i] += dw4[((t * 4) + ci) * Co + co];
+    }
+}
+}  // namespace
+
+hipError_t p3d_stem_pad(const float* x, float* x4, long long rows, int W, int Wp, int pad, hipStream_t s) {
+    hipLaunchKernelGGL(stem_pad_kernel, dim3(grid_for(rows * W)), dim3(256), 0, s, x, x4, rows, W, Wp, pad);
+    return hipGetLastError();
+}
+hipError_t p3d_stem_pack_w(const float* w, float* w4, int taps_hw, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(stem_pack_w_kernel, dim3((taps_hw * 4 * Co + 255) / 256), dim3(256), 0, s, w, w4, taps_hw, Co);
+    return hipGetLastError();
+}
+hipError_t p3d_stem_unpack_dw(const float* dw4, float* dw, int taps_hw, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(stem_unpack_dw_kernel, dim3((taps_hw * 3 * Co + 255) / 256), dim3(256), 0, s, dw4, dw, taps_hw, Co);
+    return hipGetLastError();
+}

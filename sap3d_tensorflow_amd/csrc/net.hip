@@ -599,6 +599,61 @@ struct p3d_handle {
         op.bbytes = op.bytes * (x->g ? 2 : 1);
         op.owns = {w}; if (bias) op.owns.push_back(bias);
         hipEvent_t fork_ev = new_fork_event();
+        if (stem) {
+            // firstconv1 (p3d.py:172) on the pipelined kernels: 4-channel, W-padded copy of the clip, kw*4 contiguous
+            // floats per kernel row (elementwise.hip, "stem"); 7 taps of K = 28 instead of 49 taps of K = 3
+            if (k[0] != 1 || Cin != 3 || bias) throw P3dError("stem path is for [1,kh,kw,3,C] kernels without bias");
+            const int pad_total = std::max((g.O[2] - 1) * g.s[2] + g.k[2] - g.I[2], 0);
+            const int Wp = g.I[2] + pad_total, K4 = g.k[2] * 4, KH = g.k[1];
+            const int64_t xrows = (int64_t)x->N * g.I[0] * g.I[1];
+            float* x4 = dalloc<float>(xrows * Wp * 4);
+            HIPCHECK(hipMemset(x4, 0, (size_t)xrows * Wp * 4 * sizeof(float)));
+            float* w4 = dalloc<float>((int64_t)KH * K4 * Cout);
+            float* dw4 = dalloc<float>((int64_t)KH * K4 * Cout);
+            auto geometry = [=](IgemmArgs& a) {
+                a.N = x->N; a.Di = g.I[0]; a.Hi = g.I[1]; a.Wi = Wp; a.ldx = 4; a.K = K4;
+                a.Gd = g.O[0]; a.Gh = g.O[1]; a.Gw = g.O[2]; a.isd = g.s[0]; a.ish = g.s[1]; a.isw = g.s[2];
+                a.ntaps = KH;
+                for (int kh = 0; kh < KH; ++kh) { a.taps[kh].dd = 0; a.taps[kh].dh = (int16_t)(kh - g.pad[1]); a.taps[kh].dw = 0; a.taps[kh].widx = (int16_t)kh; }
+            };
+            op.fwd = [=](const Ctx& c) {
+                launch(c, "stem_pad_kernel", 0, 28.0 * x->rows(), [&]() { return p3d_stem_pad(x->p, x4, xrows, g.I[2], Wp, g.pad[2], c.s); });
+                launch(c, "stem_pack_w_kernel", 0, 8.0 * KH * K4 * Cout, [&]() { return p3d_stem_pack_w(w->p, w4, KH * g.k[2], Cout, c.s); });
+                IgemmArgs a;
+                memset(&a, 0, sizeof(a));
+                geometry(a);
+                a.x = x4; a.y = y->p; a.Do = g.O[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.ldy = y->ld; a.Nc = Cout;
+                a.osd = a.osh = a.osw = 1; a.w = w4;
+                std::vector<IgemmArgs> v{a};
+                BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
+                static const bool sep = getenv("P3D_STEM_SEPSTATS") != nullptr;
+                if (sep && sbn) {
+                    run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, nullptr);
+                    launch(c, "bn_stats_kernel", 0, 4.0 * y->rows() * Cout, [&]() { return p3d_bn_stats(y->p, y->ld, y->rows(), Cout, bn_stats(sbn), c.s); });
+                } else
+                run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? bn_stats(sbn) : nullptr);
+            };
+            op.bwd = [=](const Ctx& c) {
+                on_side_stream(c, fork_ev, [&](const Ctx& sc) {
+                    if (!sc.dry) HIPCHECK(hipMemsetAsync(dw4, 0, (size_t)KH * K4 * Cout * sizeof(float), sc.s));
+                    IgemmArgs ga;
+                    memset(&ga, 0, sizeof(ga));
+                    geometry(ga);
+                    WgradArgs wa;
+                    memset(&wa, 0, sizeof(wa));
+                    wa.x = x4; wa.N = ga.N; wa.Di = ga.Di; wa.Hi = ga.Hi; wa.Wi = ga.Wi; wa.ldx = 4; wa.K = K4;
+                    wa.Gd = ga.Gd; wa.Gh = ga.Gh; wa.Gw = ga.Gw; wa.isd = ga.isd; wa.ish = ga.ish; wa.isw = ga.isw;
+                    wa.dy = y->g; wa.ldy = y->ld; wa.Nc = Cout; wa.dw = dw4; wa.ksplit = 1;
+                    wa.ntaps = KH;
+                    for (int kh = 0; kh < KH; ++kh) wa.taps[kh] = ga.taps[kh];
+                    launch_wgrad(sc, wa);
+                    launch(sc, "stem_unpack_dw_kernel", 0, 8.0 * KH * K4 * Cout, [&]() { return p3d_stem_unpack_dw(dw4, w->g, KH * g.k[2], Cout, sc.s); });
+                });
+                if (xflag) throw P3dError("the stem input carries no gradient");
+            };
+            ops.push_back(op);
+            return y;
+        }
         op.fwd = [=](const Ctx& c) {
             std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
                                                         nullptr, 0, stem)};

@@ -282,6 +282,10 @@ hipError_t p3d_add_inplace(float* dst, int lddst, const float* src, int ldsrc, l
 hipError_t p3d_copy_strided(float* dst, int lddst, const float* src, int ldsrc, long M, int C, hipStream_t s);
 hipError_t p3d_fill_uniform(float* p, long n, float lo, float hi, unsigned long long seed, hipStream_t s);
 hipError_t p3d_colsum(const float* dy, int ld, long M, int C, float* out, hipStream_t s);   // out += column sums
+// stem re-layout (elementwise.hip): 3-channel input -> 4-channel rows with the W padding written out; packed weights
+hipError_t p3d_stem_pad(const float* x, float* x4, long long rows, int W, int Wp, int pad, hipStream_t s);
+hipError_t p3d_stem_pack_w(const float* w, float* w4, int taps_hw, int Co, hipStream_t s);          // [kh*kw][3][Co] -> [kh*kw][4][Co]
+hipError_t p3d_stem_unpack_dw(const float* dw4, float* dw, int taps_hw, int Co, hipStream_t s);     // dw += the 3 real channels of dw4
 
 #ifdef __cplusplus
 }
