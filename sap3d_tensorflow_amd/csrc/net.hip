@@ -585,7 +585,7 @@ struct p3d_handle {
     // ---- graph ops ---------------------------------------------------------------------------
     // tf.nn.conv3d / tf.layers.conv3d: SAME conv, optional bias, optional BN-statistics epilogue.
     Act* conv(const std::string& opname, Act* x, Param* w, Param* bias, const int k[3], const int s[3], int Cout, BN* bn,
-              const std::string& out_name, bool stem = false, bool bn_has_dropout = false) {
+              const std::string& out_name, bool stem = false, bool bn_has_dropout = false, bool fwd_on_side = false) {
         const ConvGeo g = make_geo(x->D, x->H, x->W, k, s);
         Act* y = new_act(out_name, x->N, g.O[0], g.O[1], g.O[2], Cout);
         char* xflag = x->g ? consume(x) : nullptr;
@@ -654,12 +654,19 @@ struct p3d_handle {
             ops.push_back(op);
             return y;
         }
-        op.fwd = [=](const Ctx& c) {
+        auto fwd_body = [=](const Ctx& c) {
             std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
                                                         nullptr, 0, stem)};
             if (ntap == 1 && !stem && pointwise_f16) v[0].f16 = 1;
             BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
             run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? bn_stats(sbn) : nullptr);
+        };
+        // fwd_on_side: this conv has a sibling that reads the same input (ST_B, p3d.py:65-72); it runs on the side
+        // stream next to it and the caller joins the streams (join_side) before their outputs are combined
+        hipEvent_t fork_fwd = fwd_on_side ? new_fork_event() : nullptr;
+        op.fwd = [=](const Ctx& c) {
+            if (fwd_on_side && c.side && !c.dry) on_side_stream(c, fork_fwd, fwd_body);
+            else fwd_body(c);
         };
         op.bwd = [=](const Ctx& c) {
             on_side_stream(c, fork_ev, [&](const Ctx& sc) {
@@ -676,6 +683,20 @@ struct p3d_handle {
         };
         ops.push_back(op);
         return y;
+    }
+
+    // main stream waits for everything queued on the side stream so far (forward only; see conv(fwd_on_side))
+    void join_side(const std::string& opname) {
+        Op op;
+        op.name = opname; op.kind = "join";
+        hipEvent_t ev = new_fork_event();
+        op.fwd = [=](const Ctx& c) {
+            if (!c.side || c.dry) return;
+            HIPCHECK(hipEventRecord(ev, c.side));
+            HIPCHECK(hipStreamWaitEvent(c.s, ev, 0));
+        };
+        op.bwd = [](const Ctx&) {};
+        ops.push_back(op);
     }
 
     // tf.layers.conv3d_transpose(x, filters, k, s, 'same'): kernel [kd,kh,kw,Cout,Cin].
@@ -1196,11 +1217,12 @@ struct p3d_handle {
             Param* wS = conv_weight(nm + "_S", {1, 3, 3, planes, planes});
             Param* bS = conv_weight(nm + "_S_bias", {planes});
             BN* bnS = add_bn("", planes, false);
-            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "");
+            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, /*fwd_on_side=*/true);
             Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
             Param* bT = conv_weight(nm + "_T_bias", {planes});
             BN* bnT = add_bn("", planes, false);
             Act* yT = conv(B + "convT", z1, wT, bT, kT, one, planes, bnT, "");
+            join_side(B + "joinST");
             stout = bn_apply(B + "bnST", 3, yS, bnS, yT, bnT, nullptr, B + "st");
         } else {                  // p3d.py:74-81
             Param* wS = conv_weight(nm + "_S", {1, 3, 3, planes, planes});
@@ -1708,6 +1730,8 @@ struct p3d_handle {
         HIPCHECK(hipMemsetAsync(stats_arena, 0, (size_t)stats_count * sizeof(double), c.s));
         if (zf_bytes) HIPCHECK(hipMemsetAsync(zf, 0, zf_bytes, c.s));
         Ctx cz = c; cz.z0 = zf; cz.z1 = zf + zf_bytes;
+        static const bool no_side_f = getenv("P3D_NO_SIDE_STREAM") != nullptr;
+        cz.side = (c.prof || no_side_f || c.dry) ? nullptr : side_stream;      // ST_B sibling convs overlap
         const Ctx& c2 = cz;
         for (auto& op : ops) {
             if (c.prof) c.prof->cur_op = op.name;
