@@ -241,6 +241,170 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnApplyArgs a) {
     }
 }
 
+// ---- small tensors: one launch forward, one launch backward --------------------------------------------------
+// A (sample, group) slab of R rows x C/G channels that fits the registers of one block (R * C/G / 4 <= 2048 float4:
+// every GroupNorm of stage 3 at 2x7x7, the narrow ones of stage 2) needs no other block for its statistics, so the
+// stats / finalize / apply launches (and reduce / finalize / params / apply backward) collapse into one each, like
+// bn_small.hip does for BatchNorm.  grid = (G, N); thread = (channel quad of the group, row lane).  Tables
+// (scale, shift, mean, invstd per (n, c)) are still written: CBAM's block-end pass and mixed paths read them.
+constexpr int GS_MJ = 8;
+
+__device__ __forceinline__ float block_sum1(float v, float* xch4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) xch4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (xch4[0] + xch4[1]) + (xch4[2] + xch4[3]);
+}
+__device__ __forceinline__ float hsum4(float4 v) { return (v.x + v.y) + (v.z + v.w); }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_small_fwd_kernel(GnApplyArgs a) {
+    constexpr bool TWO = (MODE == 3);
+    __shared__ float xch[4];
+    const int cpg = a.C / a.g1.G, c4n = cpg >> 2, RL = 256 / c4n;
+    const int n = blockIdx.y, c = blockIdx.x * cpg + (threadIdx.x % c4n) * 4, rl = threadIdx.x / c4n;
+    const long long t = (long long)n * a.C + c;
+    const float cnt = (float)a.R * (float)cpg;
+    float4 v1[GS_MJ], v2[GS_MJ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < GS_MJ; ++j) {
+        const int r = rl + RL * j;
+        v1[j] = f4(0.f); v2[j] = f4(0.f);
+        if (r < a.R) {
+            const long long row = (long long)n * a.R + r;
+            v1[j] = ld4(a.y1 + row * a.ld1 + c);
+            s1 += hsum4(v1[j]);
+            if (MODE == 1 || MODE == 3 || MODE == 4 || MODE == 6) v2[j] = ld4(a.y2 + row * a.ld2 + c);
+            if (TWO) s2 += hsum4(v2[j]);
+        }
+    }
+    // two-pass moments from the registers
+    const float mean1 = block_sum1(s1, xch) / cnt;
+    float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < GS_MJ; ++j)
+        if (rl + RL * j < a.R) { const float4 d = sub4(v1[j], f4(mean1)); q1 += hsum4(mul4(d, d)); }
+    const float inv1 = 1.f / sqrtf(block_sum1(q1, xch) / cnt + a.eps);
+    const float4 sc1 = mul4(ld4(a.g1.gamma + c), f4(inv1));
+    const float4 sh1 = sub4(ld4(a.g1.beta + c), mul4(f4(mean1), sc1));
+    if (rl == 0) { st4(a.g1.scale + t, sc1); st4(a.g1.shift + t, sh1); st4(a.g1.mean + t, f4(mean1)); st4(a.g1.invstd + t, f4(inv1)); }
+    float4 sc2 = f4(0.f), sh2 = f4(0.f);
+    if (TWO) {
+        const float mean2 = block_sum1(s2, xch) / cnt;
+#pragma unroll
+        for (int j = 0; j < GS_MJ; ++j)
+            if (rl + RL * j < a.R) { const float4 d = sub4(v2[j], f4(mean2)); q2 += hsum4(mul4(d, d)); }
+        const float inv2 = 1.f / sqrtf(block_sum1(q2, xch) / cnt + a.eps);
+        sc2 = mul4(ld4(a.g2.gamma + c), f4(inv2));
+        sh2 = sub4(ld4(a.g2.beta + c), mul4(f4(mean2), sc2));
+        if (rl == 0) { st4(a.g2.scale + t, sc2); st4(a.g2.shift + t, sh2); st4(a.g2.mean + t, f4(mean2)); st4(a.g2.invstd + t, f4(inv2)); }
+    }
+    float4 cs = f4(0.f);
+    if (MODE == 6) cs = ld4(a.cs + t);
+#pragma unroll
+    for (int j = 0; j < GS_MJ; ++j) {
+        const int r = rl + RL * j;
+        if (r < a.R) {
+            const long long row = (long long)n * a.R + r;
+            const float4 v = fma4(sc1, v1[j], sh1);
+            float4 z;
+            if (MODE == 0) z = relu4(v);
+            else if (MODE == 5) z = v;
+            else if (MODE == 1) z = relu4(add4(v, v2[j]));
+            else if (MODE == 3) z = add4(relu4(v), relu4(fma4(sc2, v2[j], sh2)));
+            else if (MODE == 4) z = add4(v2[j], relu4(v));
+            else z = relu4(add4(v, mul4(mul4(v2[j], cs), f4(a.ss[row]))));
+            if (a.drop_scale > 0.f) z = mul4(z, dropmask4(a.seed, row * a.C + c, a.drop_rate, a.drop_scale));
+            st4(a.z + row * a.ldz + c, z);
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_small_bwd_kernel(GnApplyArgs a) {
+    constexpr bool TWO = (MODE == 3);
+    __shared__ float4 red[256][TWO ? 4 : 2];
+    __shared__ float coef[4];                       // c1, c2 of GN1 (and GN2)
+    const int cpg = a.C / a.g1.G, c4n = cpg >> 2, RL = 256 / c4n;
+    const int n = blockIdx.y, cq = threadIdx.x % c4n, c = blockIdx.x * cpg + cq * 4, rl = threadIdx.x / c4n;
+    const long long t = (long long)n * a.C + c;
+    const float cnt = (float)a.R * (float)cpg;
+    const float4 m1 = ld4(a.g1.mean + t), i1 = ld4(a.g1.invstd + t);
+    float4 m2 = f4(0.f), i2 = f4(0.f);
+    if (TWO) { m2 = ld4(a.g2.mean + t); i2 = ld4(a.g2.invstd + t); }
+    float4 g1[GS_MJ], xh1[GS_MJ], g2[GS_MJ], xh2[TWO ? GS_MJ : 1];
+    float4 s1 = f4(0.f), sx1 = f4(0.f), s2 = f4(0.f), sx2 = f4(0.f);
+#pragma unroll
+    for (int j = 0; j < GS_MJ; ++j) {
+        const int r = rl + RL * j;
+        g1[j] = f4(0.f); xh1[j] = f4(0.f); g2[j] = f4(0.f);
+        if (TWO) xh2[TWO ? j : 0] = f4(0.f);
+        if (r < a.R) {
+            const long long row = (long long)n * a.R + r;
+            float4 y1, y2;
+            gn_gates<MODE>(a, row, c, t, g1[j], g2[j], y1, y2);
+            xh1[j] = mul4(sub4(y1, m1), i1);
+            s1 = add4(s1, g1[j]); sx1 = fma4(g1[j], xh1[j], sx1);
+            if (TWO) { xh2[TWO ? j : 0] = mul4(sub4(y2, m2), i2); s2 = add4(s2, g2[j]); sx2 = fma4(g2[j], xh2[TWO ? j : 0], sx2); }
+        }
+    }
+    red[threadIdx.x][0] = s1; red[threadIdx.x][1] = sx1;
+    if (TWO) { red[threadIdx.x][2] = s2; red[threadIdx.x][3] = sx2; }
+    __syncthreads();
+    if (threadIdx.x < c4n) {                        // per-channel totals of this sample; parameter gradients add over samples
+        float4 tt[TWO ? 4 : 2];
+#pragma unroll
+        for (int k = 0; k < (TWO ? 4 : 2); ++k) tt[k] = f4(0.f);
+        for (int q = 0; q < RL; ++q)
+#pragma unroll
+            for (int k = 0; k < (TWO ? 4 : 2); ++k) tt[k] = add4(tt[k], red[q * c4n + threadIdx.x][k]);
+#pragma unroll
+        for (int k = 0; k < (TWO ? 4 : 2); ++k) red[threadIdx.x][k] = tt[k];      // (row lane 0 slot: safe, only this thread reads it)
+        const float b1[4] = {tt[0].x, tt[0].y, tt[0].z, tt[0].w}, x1[4] = {tt[1].x, tt[1].y, tt[1].z, tt[1].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(a.dbeta1 + c + k, b1[k]); unsafeAtomicAdd(a.dgamma1 + c + k, x1[k]); }
+        if (TWO) {
+            const float b2[4] = {tt[2].x, tt[2].y, tt[2].z, tt[2].w}, x2[4] = {tt[3].x, tt[3].y, tt[3].z, tt[3].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(a.dbeta2 + c + k, b2[k]); unsafeAtomicAdd(a.dgamma2 + c + k, x2[k]); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                         // gamma-weighted group sums -> the two mean terms
+        float A1 = 0.f, B1 = 0.f, A2 = 0.f, B2 = 0.f;
+        for (int q = 0; q < c4n; ++q) {
+            const float4 gm = ld4(a.g1.gamma + blockIdx.x * cpg + q * 4);
+            A1 += hsum4(mul4(gm, red[q][0])); B1 += hsum4(mul4(gm, red[q][1]));
+            if (TWO) {
+                const float4 gm2 = ld4(a.g2.gamma + blockIdx.x * cpg + q * 4);
+                A2 += hsum4(mul4(gm2, red[q][2])); B2 += hsum4(mul4(gm2, red[q][3]));
+            }
+        }
+        coef[0] = A1 / cnt; coef[1] = B1 / cnt; coef[2] = A2 / cnt; coef[3] = B2 / cnt;
+    }
+    __syncthreads();
+    const float4 k1 = mul4(ld4(a.g1.gamma + c), i1), c11 = mul4(i1, f4(coef[0])), c12 = mul4(i1, f4(coef[1]));
+    float4 k2 = f4(0.f), c21 = f4(0.f), c22 = f4(0.f);
+    if (TWO) { k2 = mul4(ld4(a.g2.gamma + c), i2); c21 = mul4(i2, f4(coef[2])); c22 = mul4(i2, f4(coef[3])); }
+#pragma unroll
+    for (int j = 0; j < GS_MJ; ++j) {
+        const int r = rl + RL * j;
+        if (r < a.R) {
+            const long long row = (long long)n * a.R + r;
+            st4(a.dy1 + row * a.lddy1 + c, sub4(sub4(mul4(k1, g1[j]), c11), mul4(xh1[j], c12)));
+            if (MODE == 1 || MODE == 3 || MODE == 4 || MODE == 6) {
+                float4 d = TWO ? sub4(sub4(mul4(k2, g2[j]), c21), mul4(xh2[TWO ? j : 0], c22)) : g2[j];
+                float* dst = a.dy2 + row * a.lddy2 + c;
+                if (a.acc2) d = add4(d, ld4(dst));
+                st4(dst, d);
+            }
+        }
+    }
+}
+
 inline unsigned grid_for(long long total, int cap = 4096) {
     long long b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -302,5 +466,24 @@ hipError_t p3d_gn_bwd_apply(const GnApplyArgs& a, hipStream_t s) {
     if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
     const dim3 g(grid_for(a.M * (a.C >> 2)));
     P3D_GN_SWITCH(gn_bwd_apply_kernel, g)
+    return hipGetLastError();
+}
+
+bool p3d_gn_small_ok(int R, int C, int G) {
+    if (G < 1 || C % G) return false;
+    const int cpg = C / G;
+    if ((cpg & 3) || (256 % (cpg >> 2))) return false;
+    return (long long)R * (cpg >> 2) <= 256 * GS_MJ;
+}
+hipError_t p3d_gn_small_fwd(const GnApplyArgs& a, hipStream_t s) {
+    if (!p3d_gn_small_ok(a.R, a.C, a.g1.G) || (a.M % a.R)) return hipErrorInvalidValue;
+    const dim3 g((unsigned)a.g1.G, (unsigned)(a.M / a.R));
+    P3D_GN_SWITCH(gn_small_fwd_kernel, g)
+    return hipGetLastError();
+}
+hipError_t p3d_gn_small_bwd(const GnApplyArgs& a, hipStream_t s) {
+    if (!p3d_gn_small_ok(a.R, a.C, a.g1.G) || (a.M % a.R)) return hipErrorInvalidValue;
+    const dim3 g((unsigned)a.g1.G, (unsigned)(a.M / a.R));
+    P3D_GN_SWITCH(gn_small_bwd_kernel, g)
     return hipGetLastError();
 }

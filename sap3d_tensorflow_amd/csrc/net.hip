@@ -962,10 +962,22 @@ struct p3d_handle {
             if (mode == 6) { a.dy2 = cb->dout; a.lddy2 = C; a.acc2 = 0; }
             else if (y2) { a.dy2 = y2->g; a.lddy2 = y2->ld; a.acc2 = *f2; }
             if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
+            a.eps = 1e-5f;
+            a.dgamma1 = g1->gamma->g; a.dbeta1 = g1->beta->g;
+            if (g2) { a.dgamma2 = g2->gamma->g; a.dbeta2 = g2->beta->g; }
             return a;
         };
+        // small tensors (every GroupNorm of stage 3): one launch each way, see gn.hip
+        static const bool no_small = getenv("P3D_NO_GN_SMALL") != nullptr;
+        const bool small = !no_small && !dropout && p3d_gn_small_ok(R, C, g1->G) && (!g2 || g2->G == g1->G);
+        const std::string ksf = "gn_small_fwd_kernel<" + std::to_string(mode) + ">";
+        const std::string ksb = "gn_small_bwd_kernel<" + std::to_string(mode) + ">";
         op.fwd = [=](const Ctx& c) {
             const GnApplyArgs a = mk(c, false);
+            if (small) {
+                launch(c, ksf.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_gn_small_fwd(a, c.s); });
+                return;
+            }
             launch(c, "gn_stats_kernel", 0, tens, [&]() { return p3d_gn_stats(y1->p, y1->ld, N, R, C, a.g1.sums, c.s); });
             launch(c, "gn_finalize_kernel", 0, 32.0 * N * C, [&]() { return p3d_gn_finalize(a.g1, N, R, 1e-5f, c.s); });
             if (mode == 3) {
@@ -976,6 +988,10 @@ struct p3d_handle {
         };
         op.bwd = [=](const Ctx& c) {
             const GnApplyArgs a = mk(c, true);
+            if (small) {
+                launch(c, ksb.c_str(), 0, tens * (y2 ? 5 : 3), [&]() { return p3d_gn_small_bwd(a, c.s); });
+                return;
+            }
             launch(c, kr.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_gn_bwd_reduce(a, c.s); });
             launch(c, "gn_bwd_finalize_kernel", 0, 64.0 * N * C, [&]() { return p3d_gn_bwd_finalize(a.g1, N, R, g1->gamma->g, g1->beta->g, c.s); });
             if (mode == 3)

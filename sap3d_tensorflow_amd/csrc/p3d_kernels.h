@@ -185,7 +185,12 @@ struct GnApplyArgs {
     float* dy1; int lddy1;
     float* dy2; int lddy2; int acc2;             // mode 3: GN2 input grad; 1,4: residual grad; 6: grad of the CBAM output
     float drop_scale; float drop_rate; unsigned long long seed;
+    // one-launch path for small tensors (p3d_gn_small_*): epsilon, and where the parameter gradients are ADDED
+    float eps; float* dgamma1; float* dbeta1; float* dgamma2; float* dbeta2;
 };
+bool p3d_gn_small_ok(int R, int C, int G);       // a (sample, group) slab fits one block's registers
+hipError_t p3d_gn_small_fwd(const GnApplyArgs& a, hipStream_t s);    // stats + tables + normalise/activate in one launch
+hipError_t p3d_gn_small_bwd(const GnApplyArgs& a, hipStream_t s);    // whole backward in one launch
 hipError_t p3d_gn_stats(const float* y, int ld, int N, int R, int C, double* sums, hipStream_t s);
 hipError_t p3d_gn_finalize(const GnParams& p, int N, int R, float eps, hipStream_t s);
 hipError_t p3d_gn_apply(const GnApplyArgs& a, hipStream_t s);
