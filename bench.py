@@ -206,6 +206,7 @@ def main():
                 print("%-28s n=%5d  %9.3f ms  avg %8.2f us  %7.2f TF/s  %8.1f GB/s" %
                       (r["kernel"], r["launches"], r["ms"], r["avg_us"], r["tflops"], r["gbs"]), file=sys.stderr)
         print(json.dumps(out), flush=True)
+    plane.barrier()        # rank 0 profiles and prints while the others wait: tear the communicators down together
     sess.close()
     plane.close()
 

@@ -2144,7 +2144,9 @@ int p3d_profile_step(p3d_handle* h, float dropout_rate, uint64_t seed, p3d_op_ti
         Ctx c; c.training = true; c.drop = dropout_rate; c.seed = seed; c.update_moving = true; c.s = h->stream; c.prof = &prof;
         prof.phase = 0; h->run_forward(c);
         prof.cur_op = "loss"; h->run_loss(c);
-        prof.phase = 1; h->run_backward(c, true);
+        // no collective here: bench.py profiles on rank 0 only, after the timed region -- an all-reduce that the
+        // other ranks do not enter would never return
+        prof.phase = 1; h->run_backward(c, false);
         prof.phase = 2; prof.cur_op = "adam"; h->run_adam(c);
         HIPCHECK(hipStreamSynchronize(c.s));
         int w = 0;
