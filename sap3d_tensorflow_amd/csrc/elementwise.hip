@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolArgs a) {
         const int oh = (int)(pos % a.Ho); pos /= a.Ho;
         const int od = (int)(pos % a.Do); const int n = (int)(pos / a.Do);
         float4 best = f4(-INFINITY);
+        unsigned bx = 0, by = 0, bz = 0, bw = 0;          // tap of the first maximum, per channel
         for (int kd = 0; kd < a.kd; ++kd) {
             const int id = od * a.sd - a.pd + kd;
             if ((unsigned)id >= (unsigned)a.Di) continue;
@@ -288,12 +289,16 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolArgs a) {
                     const int iw = ow * a.sw - a.pw + kw;
                     if ((unsigned)iw >= (unsigned)a.Wi) continue;
                     const float4 v = ld4(a.x + ((((long long)n * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.ldx + c);
-                    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
-                    best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+                    const unsigned t = (unsigned)((kd * a.kh + kh) * a.kw + kw);
+                    if (v.x > best.x) { best.x = v.x; bx = t; }
+                    if (v.y > best.y) { best.y = v.y; by = t; }
+                    if (v.z > best.z) { best.z = v.z; bz = t; }
+                    if (v.w > best.w) { best.w = v.w; bw = t; }
                 }
             }
         }
         st4(a.y + opos * a.ldy + c, best);
+        if (a.idx) a.idx[opos * c4n + (c >> 2)] = bx | (by << 8) | (bz << 16) | (bw << 24);
     }
 }
 
@@ -528,6 +533,43 @@ __global__ __launch_bounds__(256) void maxpool_bwd_disjoint_kernel(PoolArgs a, i
     }
 }
 
+// Overlapping windows (pool1, p3d.py:177: k = [2,3,3], s = 2): thread = one input cell x 4 channels; it visits the
+// windows that contain the cell (at most ceil(k/s) per axis) and takes dy where the stored arg-max tap is its own.
+__global__ __launch_bounds__(256) void maxpool_bwd_gather_kernel(PoolArgs a, int accumulate) {
+    const int c4n = a.C >> 2;
+    const long long total = (long long)a.N * a.Di * a.Hi * a.Wi * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long pos = i / c4n;
+        const int c = (int)(i - pos * c4n) << 2;
+        const long long ipos = pos;
+        const int iw = (int)(pos % a.Wi); pos /= a.Wi;
+        const int ih = (int)(pos % a.Hi); pos /= a.Hi;
+        const int id = (int)(pos % a.Di); const int n = (int)(pos / a.Di);
+        const int pdv = id + a.pd, phv = ih + a.ph, pwv = iw + a.pw;
+        float4 acc = f4(0.f);
+        for (int od = pdv / a.sd; od >= 0 && pdv - od * a.sd < a.kd; --od) {
+            if (od >= a.Do) continue;
+            for (int oh = phv / a.sh; oh >= 0 && phv - oh * a.sh < a.kh; --oh) {
+                if (oh >= a.Ho) continue;
+                for (int ow = pwv / a.sw; ow >= 0 && pwv - ow * a.sw < a.kw; --ow) {
+                    if (ow >= a.Wo) continue;
+                    const unsigned t = (unsigned)(((pdv - od * a.sd) * a.kh + (phv - oh * a.sh)) * a.kw + (pwv - ow * a.sw));
+                    const long long opos = (((long long)n * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+                    const unsigned w = a.idx[opos * c4n + (c >> 2)];
+                    const float4 g = ld4(a.dy + opos * a.lddy + c);
+                    if ((w & 255u) == t) acc.x += g.x;
+                    if (((w >> 8) & 255u) == t) acc.y += g.y;
+                    if (((w >> 16) & 255u) == t) acc.z += g.z;
+                    if ((w >> 24) == t) acc.w += g.w;
+                }
+            }
+        }
+        float* dst = a.dx + ipos * a.lddx + c;
+        if (accumulate) acc = add4(acc, ld4(dst));
+        st4(dst, acc);
+    }
+}
+
 bool p3d_maxpool_disjoint(const PoolArgs& a) {
     return a.kd == a.sd && a.kh == a.sh && a.kw == a.sw && a.pd == 0 && a.ph == 0 && a.pw == 0 &&
            a.Do * a.sd == a.Di && a.Ho * a.sh == a.Hi && a.Wo * a.sw == a.Wi;
@@ -632,5 +674,12 @@ hipError_t p3d_stem_pack_w(const float* w, float* w4, int taps_hw, int Co, hipSt
 }
 hipError_t p3d_stem_unpack_dw(const float* dw4, float* dw, int taps_hw, int Co, hipStream_t s) {
     hipLaunchKernelGGL(stem_unpack_dw_kernel, dim3((taps_hw * 3 * Co + 255) / 256), dim3(256), 0, s, dw4, dw, taps_hw, Co);
+    return hipGetLastError();
+}
+
+hipError_t p3d_maxpool_bwd_gather(const PoolArgs& a, int accumulate, hipStream_t s) {
+    if ((a.C & 3) || !a.idx || a.kd * a.kh * a.kw > 250) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.Di * a.Hi * a.Wi * (a.C >> 2);
+    hipLaunchKernelGGL(maxpool_bwd_gather_kernel, dim3(grid_for(total)), dim3(256), 0, s, a, accumulate);
     return hipGetLastError();
 }

@@ -875,6 +875,13 @@ struct p3d_handle {
         if (!out) out = new_act(out_name, x->N, g.O[0], g.O[1], g.O[2], x->C);
         else if (!out_name.empty()) named[out_name] = out;
         char* xflag = consume(x);
+        // overlapping windows (pool1): the forward keeps the arg-max tap of every output so that the backward can gather
+        unsigned* idx = nullptr;
+        {
+            const bool disjoint = g.k[0] == g.s[0] && g.k[1] == g.s[1] && g.k[2] == g.s[2] && !g.pad[0] && !g.pad[1] && !g.pad[2] &&
+                                  g.O[0] * g.s[0] == g.I[0] && g.O[1] * g.s[1] == g.I[1] && g.O[2] * g.s[2] == g.I[2];
+            if (!disjoint) idx = (unsigned*)dalloc<float>(out->rows() * (x->C / 4));
+        }
         Op op;
         op.name = opname; op.kind = "maxpool";
         op.bytes = 4.0 * (x->rows() + out->rows()) * x->C;
@@ -888,6 +895,7 @@ struct p3d_handle {
             a.kd = g.k[0]; a.kh = g.k[1]; a.kw = g.k[2]; a.sd = g.s[0]; a.sh = g.s[1]; a.sw = g.s[2];
             a.pd = g.pad[0]; a.ph = g.pad[1]; a.pw = g.pad[2];
             a.dy = out->g; a.lddy = out->ld; a.dx = x->g; a.lddx = x->ld;
+            a.idx = idx;
             return a;
         };
         const double pool_bytes = op.bytes;
@@ -896,6 +904,10 @@ struct p3d_handle {
             const PoolArgs pa = mk();
             if (p3d_maxpool_disjoint(pa)) {
                 launch(c, "maxpool_bwd_disjoint_kernel", 0, pool_bytes * 2, [&]() { return p3d_maxpool_bwd_disjoint(pa, *xflag, c.s); });
+                return;
+            }
+            if (pa.idx) {
+                launch(c, "maxpool_bwd_gather_kernel", 0, pool_bytes * 2, [&]() { return p3d_maxpool_bwd_gather(pa, *xflag, c.s); });
                 return;
             }
             if (!*xflag) zero_strided(c, x->g, x->ld, x->rows(), x->C);

@@ -250,8 +250,13 @@ struct PoolArgs {
     int kd, kh, kw, sd, sh, sw, pd, ph, pw;
     // backward
     const float* dy; int lddy; float* dx; int lddx;
+    unsigned* idx;       // optional [N*Do*Ho*Wo][C/4] words, one byte per channel: tap (kd,kh,kw scan order) of the
+                         // first maximum; written by the forward, read by p3d_maxpool_bwd_gather
 };
 hipError_t p3d_maxpool_fwd(const PoolArgs& a, hipStream_t s);
+// overlapping windows without atomics or a zero fill: every input cell collects from the (few) windows that contain it,
+// using the arg-max taps the forward stored.  Writes dx, or adds to it (accumulate = 1).
+hipError_t p3d_maxpool_bwd_gather(const PoolArgs& a, int accumulate, hipStream_t s);
 hipError_t p3d_maxpool_bwd(const PoolArgs& a, hipStream_t s);   // atomically adds into dx
 bool p3d_maxpool_disjoint(const PoolArgs& a);                    // k == s, no padding: windows do not overlap
 hipError_t p3d_maxpool_bwd_disjoint(const PoolArgs& a, int accumulate, hipStream_t s);   // writes / accumulates dx, no atomics
