@@ -1620,19 +1620,20 @@ struct p3d_handle {
             return a;
         };
         const double hf = op.flops, hb = op.bytes;
+        hipEvent_t head_fork = new_fork_event();
         op.fwd = [=](const Ctx& c) {
             if (transpose) launch(c, "head_fwd_kernel", hf, hb, [&]() { return p3d_head_fwd(mk(), c.s); });
             else launch(c, "headc_fwd_kernel", hf, hb, [&]() { return p3d_headc_fwd(mk(), c.s); });
         };
         op.bwd = [=](const Ctx& c) {
             if (*xflag) throw P3dError("head input gradient must be the first writer");
-            if (transpose) {
-                launch(c, "head_bwd_filter_kernel", hf, hb, [&]() { return p3d_head_bwd_filter(mk(), c.s); });
-                launch(c, "head_bwd_input_kernel", hf, hb, [&]() { return p3d_head_bwd_input(mk(), c.s); });
-            } else {
-                launch(c, "headc_bwd_filter_kernel", hf, hb, [&]() { return p3d_headc_bwd_filter(mk(), c.s); });
-                launch(c, "headc_bwd_input_kernel", hf, hb, [&]() { return p3d_headc_bwd_input(mk(), c.s); });
-            }
+            // the filter gradient is a weight gradient like any other: side stream, off the critical path
+            on_side_stream(c, head_fork, [&](const Ctx& sc) {
+                if (transpose) launch(sc, "head_bwd_filter_kernel", hf, hb, [&]() { return p3d_head_bwd_filter(mk(), sc.s); });
+                else launch(sc, "headc_bwd_filter_kernel", hf, hb, [&]() { return p3d_headc_bwd_filter(mk(), sc.s); });
+            });
+            if (transpose) launch(c, "head_bwd_input_kernel", hf, hb, [&]() { return p3d_head_bwd_input(mk(), c.s); });
+            else launch(c, "headc_bwd_input_kernel", hf, hb, [&]() { return p3d_headc_bwd_input(mk(), c.s); });
         };
         ops.push_back(op);
     }
