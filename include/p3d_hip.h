@@ -114,6 +114,14 @@ int p3d_set_adam(p3d_handle* h, float lr, float beta1, float beta2, float eps);
 int p3d_activation_info(p3d_handle* h, const char* name, int64_t shape[5]);
 int p3d_get_activation(p3d_handle* h, const char* name, float* host, int64_t count);
 
+/* ---- one bottleneck in isolation (BASELINE.json configs[0], SURVEY.md 8d cfg 1 "standalone variant"): the forward of
+ *      Bottleneck(...).infer() (p3d.py:83-136; gn/p3d_gn.py:127-179 for the GN structures) number `block_id`
+ *      (0 .. sum(blocks)-1) of this handle's graph on a caller-supplied input, with the handle's current parameters.
+ *      Shapes are those the block has inside the graph (p3d_block_info).  BatchNorm uses batch statistics, as
+ *      everywhere in the backbone. */
+int p3d_block_info(p3d_handle* h, int block_id, int64_t in_shape[5], int64_t out_shape[5]);
+int p3d_block_forward(p3d_handle* h, int block_id, const float* in, int64_t in_count, float* out, int64_t out_count);
+
 /* ---- device-resident stepping for measurement: inputs already in HBM (bench.py).
  *      p3d_device_inputs returns the handle's own x / y staging buffers (device pointers,
  *      [B,T,H,W,3] and [B,T,H,W] floats); fill them once with p3d_upload_inputs, then call

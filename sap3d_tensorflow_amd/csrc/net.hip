@@ -1082,6 +1082,12 @@ struct p3d_handle {
 
     // Bottleneck.infer of the GN file, gn/p3d_gn.py:127-179
     Act* bottleneck_gn(Act* x, int id, int inplanes, int planes, bool first, bool stride2) {
+        blocks[id].in = x; blocks[id].op0 = ops.size();
+        Act* r = bottleneck_gn_body(x, id, inplanes, planes, first, stride2);
+        blocks[id].out = r; blocks[id].op1 = ops.size();
+        return r;
+    }
+    Act* bottleneck_gn_body(Act* x, int id, int inplanes, int planes, bool first, bool stride2) {
         const std::string sid = std::to_string(id);
         const char st = "ABC"[id % 3];
         const int one[3] = {1, 1, 1}, s2[3] = {1, 2, 2};
@@ -1215,7 +1221,16 @@ struct p3d_handle {
     Param* conv_weight(const std::string& name, std::vector<int64_t> shape) { return add_param(name, shape, true, INIT_XAVIER); }
 
     // Bottleneck.infer, p3d.py:83-136 (3-D branch only; the 2-D branch is unreachable)
+    // per bottleneck: input / output tensors and the [first, last) range of its ops, for p3d_block_forward
+    struct BlockInfo { Act* in = nullptr; Act* out = nullptr; size_t op0 = 0, op1 = 0; };
+    std::map<int, BlockInfo> blocks;
     Act* bottleneck(Act* x, int id, int inplanes, int planes, bool first, bool stride2) {
+        blocks[id].in = x; blocks[id].op0 = ops.size();
+        Act* r = bottleneck_body(x, id, inplanes, planes, first, stride2);
+        blocks[id].out = r; blocks[id].op1 = ops.size();
+        return r;
+    }
+    Act* bottleneck_body(Act* x, int id, int inplanes, int planes, bool first, bool stride2) {
         const std::string sid = std::to_string(id);
         const char st = "ABC"[id % 3];
         const int one[3] = {1, 1, 1};
@@ -2146,6 +2161,33 @@ int p3d_get_activation(p3d_handle* h, const char* name, float* host, int64_t cou
     if (count != a->rows() * a->C) throw P3dError("activation size mismatch");
     HIPCHECK(hipSetDevice(h->cfg.device));
     h->download_act(a, host);
+    API_END
+}
+
+int p3d_block_info(p3d_handle* h, int block_id, int64_t in_shape[5], int64_t out_shape[5]) {
+    API_BEGIN
+    if (!h) throw P3dError("null handle");
+    auto it = h->blocks.find(block_id);
+    if (it == h->blocks.end()) throw P3dError("no bottleneck with id " + std::to_string(block_id));
+    const Act* a = it->second.in; const Act* b = it->second.out;
+    if (in_shape) { in_shape[0] = a->N; in_shape[1] = a->D; in_shape[2] = a->H; in_shape[3] = a->W; in_shape[4] = a->C; }
+    if (out_shape) { out_shape[0] = b->N; out_shape[1] = b->D; out_shape[2] = b->H; out_shape[3] = b->W; out_shape[4] = b->C; }
+    API_END
+}
+
+int p3d_block_forward(p3d_handle* h, int block_id, const float* in, int64_t in_count, float* out, int64_t out_count) {
+    API_BEGIN
+    if (!h || !in || !out) throw P3dError("null argument");
+    auto it = h->blocks.find(block_id);
+    if (it == h->blocks.end()) throw P3dError("no bottleneck with id " + std::to_string(block_id));
+    Act* a = it->second.in; Act* b = it->second.out;
+    if (in_count != a->rows() * a->C || out_count != b->rows() * b->C) throw P3dError("block tensor size mismatch");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    HIPCHECK(hipMemcpy2DAsync(a->p, (size_t)a->ld * 4, in, (size_t)a->C * 4, (size_t)a->C * 4, (size_t)a->rows(), hipMemcpyHostToDevice, h->stream));
+    Ctx c; c.training = true; c.s = h->stream;
+    HIPCHECK(hipMemsetAsync(h->stats_arena, 0, (size_t)h->stats_count * sizeof(double), c.s));
+    for (size_t i = it->second.op0; i < it->second.op1; ++i) h->ops[i].fwd(c);      // (no zero arena: ops zero what they slice)
+    h->download_act(b, out);
     API_END
 }
 

@@ -118,6 +118,22 @@ class P3DSession:
         check(lib().p3d_forward(self._h, fptr(x), int(bool(training)), float(dropout), seed, fptr(pred)))
         return pred
 
+    def block_shapes(self, block_id):
+        """(input shape, output shape) of bottleneck `block_id` inside this graph."""
+        ishape, oshape = (C.c_int64 * 5)(), (C.c_int64 * 5)()
+        check(lib().p3d_block_info(self._h, int(block_id), ishape, oshape))
+        return tuple(ishape), tuple(oshape)
+
+    def block_forward(self, block_id, x):
+        """Bottleneck `block_id` of this graph in isolation (p3d.py:83-136) on input x [B,D,H,W,inplanes]."""
+        ishape, oshape = self.block_shapes(block_id)
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        if a.shape != ishape:
+            raise ValueError("block %d takes %s, got %s" % (block_id, ishape, a.shape))
+        out = np.empty(oshape, np.float32)
+        check(lib().p3d_block_forward(self._h, int(block_id), fptr(a), a.size, fptr(out), out.size))
+        return out
+
     def set_pointwise_fp16(self, enable=True):
         """BASELINE configs[4]: 1x1x1 convs on the fp16 matrix cores (fp32 accumulate, fp32 storage); fp16-level parity."""
         check(lib().p3d_set_pointwise_fp16(self._h, int(bool(enable))))

@@ -562,3 +562,39 @@ def test_pointwise_fp16_mode():
     again = s.forward(x, 0.0, True)
     assert np.abs(again - full).max() < 1e-5
     s.close()
+
+
+@pytest.mark.parametrize("block_id", [0, 1, 2, 3, 4, 7])
+def test_block_forward_standalone(block_id):
+    """BASELINE.json configs[0] / SURVEY.md 8d cfg 1, standalone variant: ONE bottleneck (p3d.py:83-136) on an N(0,1)
+    input, through p3d_block_forward, against the oracle's Bottleneck.infer() with the same variables.  Ids 0 / 3
+    are the projected (and, for 3, strided) first blocks of a stage; 0,1,2 are types A,B,C."""
+    from oracle import nn
+    cfg, shape = p3d.NetConfig(base=16, blocks=(3, 3, 2)), (2, 16, 32, 32)
+    p64 = randomise_norm_params(p3d.init_params(1, 'unet', cfg, dtype=np.float64))
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    s = make_session(cfg, shape, p32)
+    b = cfg.base
+    stage = 0 if block_id < 3 else (1 if block_id < 6 else 2)
+    first = block_id in (0, 3, 6)
+    planes = (b, 2 * b, 4 * b)[stage]
+    inplanes = b if block_id == 0 else (4 * (b, 2 * b, 4 * b)[stage - 1] if first else 4 * planes)
+    ishape, _ = s.block_shapes(block_id)
+    assert ishape[0] == shape[0] and ishape[4] == inplanes
+    x = np.random.default_rng(2).standard_normal(ishape).astype(np.float32)
+    got = s.block_forward(block_id, x)
+    s.close()
+    # oracle: the same Bottleneck with the graph's variables; BN scopes are auto-numbered, so start the counter at
+    # the first batch_normalization_<k> that follows this block's first conv in creation order
+    names = list(p64)
+    k0 = names.index('conv3_%d_1' % block_id)
+    bn = next(n for n in names[k0:] if n.startswith('batch_normalization') and n.endswith('/gamma')).split('/')[0]
+    g = p3d.Graph(p64, dtype=np.float64, create=False)
+    g._uniq['batch_normalization'] = int(bn.split('_')[-1]) if '_' in bn[len('batch_normalization'):] else 0
+    X = nn.Var(x.astype(np.float64))
+    if first:       # the first block of a stage goes through make_block's stride / projection bookkeeping (p3d.py:139-158)
+        want = p3d.make_block(g, X, planes, 1, inplanes, block_id, stride=2 if stage > 0 else 1).infer().data
+    else:
+        want = p3d.Bottleneck(g, X, inplanes, planes, n_s=block_id).infer().data
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)
