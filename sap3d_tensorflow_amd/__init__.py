@@ -3,3 +3,4 @@ functions and the session calls around them).  All arithmetic runs in libp3dhip.
 from ._lib import LIB_PATH, P3dError, lib        # noqa: F401
 from .session import P3DSession                  # noqa: F401
 from . import ops                                # noqa: F401
+from . import p3d, p3d_gn                        # noqa: F401  (eager mirrors of the reference's graph functions)

@@ -598,3 +598,28 @@ def test_block_forward_standalone(block_id):
         want = p3d.Bottleneck(g, X, inplanes, planes, n_s=block_id).infer().data
     assert got.shape == want.shape
     assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)
+
+
+def test_eager_graph_function_mirrors():
+    """sap3d_tensorflow_amd.p3d / p3d_gn expose the reference's function names and arguments (p3d.py:169,224,340,401;
+    gn/p3d_gn.py:214,279,489) eagerly; each must return what its cached session's forward returns, and the variables
+    must be reachable for checkpoints."""
+    from sap3d_tensorflow_amd import p3d as hp, p3d_gn as hg
+    x = p3d.synthetic_clip(0, (1, 16, 32, 32, 3))
+    try:
+        a = hp.p3d_unet(x, 0.0, batch_size=1, training=False)
+        s = hp.session_for("unet", x.shape)
+        assert a.shape == (1, 16, 32, 32, 1) and np.abs(a - s.forward(x, 0.0, False)).max() < 2e-2
+        # (not bitwise: at 32x32 the reference architecture's stage 3 normalises over 1x2x2 = 4 positions per channel, and
+        #  36 such blocks amplify the split-K atomics' 1e-7 reordering noise to ~3e-3 on the maps)
+        assert 0.0 < a.min() and a.max() < 1.0
+        assert 'firstconv1' in s.save()
+        assert hp.p3d_concat(x, 0.0, 1, False).shape == (1, 16, 32, 32, 1)
+        assert hp.p3d_unetplusplus_nonsa(x, 0.0, 1, False).shape == (1, 16, 32, 32, 1)
+        assert hg.inference_p3d(x, 0.0, 1, False).shape == (1, 16, 32, 32, 1)
+        with pytest.raises(NotImplementedError):
+            hp.p3d_unetplusplus(x, 0.0, 1, False)
+        with pytest.raises(ValueError):
+            hp.p3d_unet(x, 0.0, batch_size=2, training=False)
+    finally:
+        hp.reset()
