@@ -20,8 +20,11 @@ sys.path.insert(0, ROOT)
 
 def get_arguments():
     p = argparse.ArgumentParser(description="P3D saliency trainer (MI355X-native)")
-    p.add_argument("--normalization", type=str, default="bn", help="bn -> p3d.py graphs, gn -> gn/p3d_gn.py inference_p3d")
-    p.add_argument("--structure", type=str, default="unet", help="unet | concat | unet++nonsa (train.py:149-154; unet++ without its attention blocks, p3d.py:401)")
+    p.add_argument("--normalization", type=str, default="BN", help="BN -> p3d.py graphs, GN -> gn/p3d_gn.py nets (train.py:37; case-insensitive)")
+    p.add_argument("--structure", type=str, default="unet",
+                   help="unet | concat | unet++ (train.py:149-154).  unet++ builds p3d_unetplusplus_ds with --SA True (the attention head "
+                        "that can be built, p3d.py:340) and p3d_unetplusplus_nonsa with --SA False (p3d.py:401); both can also be named directly")
+    p.add_argument("--SA", type=lambda v: str(v).lower() in ("1", "true", "yes"), default=True, help="self attention in the unet++ head (train.py:38)")
     p.add_argument("--net", type=str, default="P3D", help="with --normalization gn: P3D | P3D_CONCAT | P3D_DECODER (gn/train_p3d_gn_dataset.py:30,169-180)")
     p.add_argument("--batch", type=int, default=2)
     p.add_argument("--lr", type=float, default=1e-4)
@@ -32,6 +35,13 @@ def get_arguments():
     p.add_argument("--validiter", type=int, default=1000)
     p.add_argument("--plotiter", type=int, default=1000)
     p.add_argument("--info", type=str, default="run")
+    # accepted for command-line compatibility with train.py:29-34; they drive the reference's dataset pipeline, which is
+    # out of scope here, except for the clip geometry
+    p.add_argument("--trainingprops", type=float, default=0.99)
+    p.add_argument("--dataset", type=str, default="svsdndhf1k")
+    p.add_argument("--videolength", type=int, default=16, help="frames per clip (train.py:32)")
+    p.add_argument("--overlap", type=int, default=15)
+    p.add_argument("--imagesize", type=int, nargs=2, default=(112, 112), help="clip height width (train.py:34)")
     p.add_argument("--data", type=str, default="", help="npz with x, y; empty = synthetic clips")
     p.add_argument("--steps", type=int, default=20, help="steps per epoch when synthetic")
     return p.parse_args()
@@ -49,17 +59,25 @@ def batches(args, rng):
                 yield x[idx], y[idx]
     else:
         for s in range(args.epoch * args.steps):
-            yield (law.synthetic_clip(s, (args.batch, 16, 112, 112, 3)), law.synthetic_target(10_000 + s, (args.batch, 16, 112, 112)))
+            shape = (args.batch, args.videolength, args.imagesize[0], args.imagesize[1])
+            yield law.synthetic_clip(s, shape + (3,)), law.synthetic_target(10_000 + s, shape)
 
 
 def main():
     args = get_arguments()
     from sap3d_tensorflow_amd import P3DSession
     gn_nets = {"P3D": "gn_p3d", "P3D_CONCAT": "gn_p3d_concat", "P3D_DECODER": "gn_p3d_decoder"}     # gn/train_p3d_gn_dataset.py:169-180
-    if args.normalization == "gn" and args.net not in gn_nets:
-        raise SystemExit("--net %s is not built (attention heads, SURVEY.md row N2); have %s" % (args.net, sorted(gn_nets)))
-    structure = gn_nets[args.net] if args.normalization == "gn" else args.structure
-    sess = P3DSession(structure, batch=args.batch, device=int(args.gpu), seed=0)      # graph + global_variables_initializer
+    gn = args.normalization.lower() == "gn"
+    if gn and args.net not in gn_nets:
+        raise SystemExit("--net %s is not built (its attention() calls do not match utils/network.py:157 and cannot build "
+                         "in the reference either); have %s" % (args.net, sorted(gn_nets)))
+    structure = args.structure
+    if structure == "unet++":                                                        # train.py:153-154
+        structure = "unet++ds" if args.SA else "unet++nonsa"
+    if gn:
+        structure = gn_nets[args.net]
+    sess = P3DSession(structure, batch=args.batch, frames=args.videolength, height=args.imagesize[0], width=args.imagesize[1],
+                      device=int(args.gpu), seed=0)                                  # graph + global_variables_initializer
     sess.set_adam(args.lr)
     model_dir = os.path.join("model", args.info)
     os.makedirs(model_dir, exist_ok=True)
