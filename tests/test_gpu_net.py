@@ -623,3 +623,58 @@ def test_eager_graph_function_mirrors():
             hp.p3d_unet(x, 0.0, batch_size=2, training=False)
     finally:
         hp.reset()
+
+
+def test_gn_block_forward_standalone():
+    """The GN / CBAM bottleneck (gn/p3d_gn.py:127-179) in isolation through p3d_block_forward, against the oracle's
+    Bottleneck.infer() -- a type-B block with identity residual (CBAM still applies to it, gn/p3d_gn.py:175)."""
+    from oracle import nn, p3d_gn
+    cfg, shape = GN_SMALL[1]
+    p64 = _gn_params(cfg, np.float64)
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    s = make_session(cfg, shape, p32, 'gn_p3d')
+    block_id = 4                                   # blocks (1,2,3): stage 3 = ids 3,4,5; id 4 is type B, not first
+    ishape, _ = s.block_shapes(block_id)
+    x = np.random.default_rng(2).standard_normal(ishape).astype(np.float32)
+    got = s.block_forward(block_id, x)
+    s.close()
+    names = list(p64)
+    k0 = names.index('conv3_%d_1' % block_id)
+    gn = next(n for n in names[k0:] if n.startswith('group_norm') and n.endswith('/gamma')).split('/')[0]
+    g = p3d.Graph(p64, dtype=np.float64, create=False)
+    g._uniq['group_norm'] = int(gn.split('_')[-1])
+    planes = 4 * cfg.base
+    want = p3d_gn.Bottleneck(g, nn.Var(x.astype(np.float64)), 4 * planes, planes, n_s=block_id).infer().data
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)
+
+
+def test_gen_pred_driver_on_gpu(tmp_path):
+    """drivers/gen_pred.py end to end on a synthetic 20-frame video: window batching through p3d_predict_windows must
+    give, frame by frame, what the reference's one-window-per-run loop gives (gen_pred.py:100-168)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_pred", os.path.join(root, "drivers", "gen_pred.py"))
+    gp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gp)
+    from sap3d_tensorflow_amd import P3DSession
+    video = np.random.default_rng(0).integers(0, 256, (20, 120, 160, 3)).astype(np.uint8)
+    frames = gp.preprocess(video)                                  # [20,112,112,3]
+    kw = dict(base=16, blocks=(1, 1, 2))
+    sb = P3DSession("unet", batch=3, seed=4, **kw)
+    out = gp.predict_video(sb, frames, batch=3)
+    params = sb.save()
+    sb.close()
+    s1 = P3DSession("unet", batch=1, **kw)
+    s1.load(params)
+    want = np.zeros_like(out)
+    for start in range(20 - 15):
+        m = s1.forward(frames[start:start + 16][None], 0.0, False)[0, ..., 0]
+        if start == 0:
+            want[:16] = m
+        else:
+            want[start + 15] = m[-1]
+    s1.close()
+    assert out.shape == (20, 112, 112)
+    assert np.abs(out - want).max() < 2e-5
