@@ -146,10 +146,15 @@ def main():
 
     B = args.batch
     T, S = args.frames, args.size
-    sess = P3DSession(args.structure, batch=B, frames=T, height=S, width=S, device=local_rank, world_size=world, rank=rank, seed=1)
+    # Rehearsal of the multi-process launch on a ONE-GPU box (torch.distributed.run, rendezvous, barriers, rank-0 output):
+    # every rank uses device 0 and no RCCL communicator is built (RCCL refuses two ranks on one device), so gradients
+    # stay local.  The printed value is meaningless and says so.
+    rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1"
+    sess = P3DSession(args.structure, batch=B, frames=T, height=S, width=S, device=0 if rehearsal else local_rank,
+                      world_size=world, rank=rank, seed=1)
     if args.pointwise == "fp16":
         sess.set_pointwise_fp16(True)
-    if world > 1:
+    if world > 1 and not rehearsal:
         sess.comm_init(plane.share_from_rank0(P3DSession.comm_unique_id))
     x = synthetic.synthetic_clip(rank, (B, T, S, S, 3))
     y = synthetic.synthetic_target(3 + rank, (B, T, S, S))
@@ -182,6 +187,7 @@ def main():
             "metric": "clips/s (16x112x112 fwd+bwd)", "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            **({"rehearsal": "all ranks on device 0, no all-reduce: NOT a measurement"} if rehearsal else {}),
             "dtype": "f32" if args.pointwise == "fp32" else "f32 (1x1x1 convs: fp16 MFMA operands, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "%s train step: fwd + Smooth-L1 + bwd + Adam, %dx%dx%dx3 clips, batch %d per GPU (%s)" %
                                    ({"unet": "p3d_unet (P3D-199 encoder + unet decoder)", "concat": "p3d_concat",
