@@ -68,6 +68,25 @@ SIGNATURES = {
 }
 
 
+def _one_rocm_runtime_per_process():
+    """Load order guard.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 / librccl (torch/lib).
+    Loading libp3dhip.so BEFORE torch ends in `double free or corruption` at interpreter exit (tools/dupe_probe.py):
+    first because two HIP runtimes get loaded (system + bundled), and -- even with a single runtime -- because
+    libp3dhip's HIP fat-binary un-registration (an atexit handler hipcc emits) then runs after torch has torn the
+    runtime down.  With torch loaded first both problems vanish: libp3dhip binds to the already loaded runtime by
+    soname and un-registers before torch's teardown.  So if a torch installation is present it is imported here,
+    before the library -- the order bench.py has at N > 1 anyway (torch.distributed comes first there)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:       # a broken torch installation must not take the HIP path down with it
+        pass
+
+
 def lib():
     """Load libp3dhip.so once.  Raises if it has not been built (python -m sap3d_tensorflow_amd.build)."""
     global _lib
@@ -75,6 +94,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise P3dError("libp3dhip.so is not built (%s); run `python sap3d_tensorflow_amd/build.py`. "
                            "There is no CPU fallback." % LIB_PATH)
+        _one_rocm_runtime_per_process()
         l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
