@@ -35,16 +35,26 @@ __device__ __forceinline__ float4 dropmask4(unsigned long long seed, long long e
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(BnParams bn, double invM, int use_batch, int update_moving, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= bn.C) return;
+// 16 lanes per channel: lane r loads replica r, the 16 are folded with shuffles (one load latency instead of a chain
+// of 16); lane 0 of the group finishes the channel.  These tiny kernels sit on the critical path ~100 times per step.
+static_assert(P3D_STAT_REPLICAS == 16, "finalize kernels fold 16 replicas with 4 shuffle steps");
+__device__ __forceinline__ double fold16(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnParams bn, double invM, int use_batch, int update_moving, float eps) {
+    const int r = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = c < bn.C;
+    double s1 = 0.0, s2 = 0.0;
+    if (use_batch) {
+        if (ok) { s1 = bn.stats[(size_t)r * 2 * bn.C + 2 * c]; s2 = bn.stats[(size_t)r * 2 * bn.C + 2 * c + 1]; }
+        s1 = fold16(s1); s2 = fold16(s2);
+    }
+    if (!ok || r) return;
     double mean, var;
     if (use_batch) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < P3D_STAT_REPLICAS; ++r) {
-            s1 += bn.stats[(size_t)r * 2 * bn.C + 2 * c];
-            s2 += bn.stats[(size_t)r * 2 * bn.C + 2 * c + 1];
-        }
         mean = s1 * invM;
         var = s2 * invM - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -196,25 +206,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 
 // Folds the replicated sums: coef[c] = (sum g / M, sum g*xhat / M) and the BN parameter gradients
 // (each BN parameter is produced exactly once per step, so they are written, not accumulated).
-__global__ void bn_bwd_finalize_kernel(BnBwdArgs a, int two) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int two) {
+    const int r = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = c < a.C;
     const double invM = 1.0 / (double)a.M;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < P3D_STAT_REPLICAS; ++r) {
-        s1 += a.red1[(size_t)r * 2 * a.C + 2 * c];
-        s2 += a.red1[(size_t)r * 2 * a.C + 2 * c + 1];
+    double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
+    if (ok) {
+        s1 = a.red1[(size_t)r * 2 * a.C + 2 * c]; s2 = a.red1[(size_t)r * 2 * a.C + 2 * c + 1];
+        if (two) { t1 = a.red2[(size_t)r * 2 * a.C + 2 * c]; t2 = a.red2[(size_t)r * 2 * a.C + 2 * c + 1]; }
     }
+    s1 = fold16(s1); s2 = fold16(s2);
+    if (two) { t1 = fold16(t1); t2 = fold16(t2); }
+    if (!ok || r) return;
     a.dbeta1[c] = (float)s1; a.dgamma1[c] = (float)s2;
     a.coef1[2 * c] = (float)(s1 * invM); a.coef1[2 * c + 1] = (float)(s2 * invM);
     if (two) {
-        s1 = 0.0; s2 = 0.0;
-        for (int r = 0; r < P3D_STAT_REPLICAS; ++r) {
-            s1 += a.red2[(size_t)r * 2 * a.C + 2 * c];
-            s2 += a.red2[(size_t)r * 2 * a.C + 2 * c + 1];
-        }
-        a.dbeta2[c] = (float)s1; a.dgamma2[c] = (float)s2;
-        a.coef2[2 * c] = (float)(s1 * invM); a.coef2[2 * c + 1] = (float)(s2 * invM);
+        a.dbeta2[c] = (float)t1; a.dgamma2[c] = (float)t2;
+        a.coef2[2 * c] = (float)(t1 * invM); a.coef2[2 * c + 1] = (float)(t2 * invM);
     }
 }
 
@@ -427,7 +436,7 @@ inline unsigned grid_for(long long total, int per_block = 256, int cap = 4096) {
 }  // namespace
 
 hipError_t p3d_bn_finalize(const BnParams& bn, long M, int use_batch, int update_moving, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((bn.C + 255) / 256), dim3(256), 0, s, bn, 1.0 / (double)M, use_batch,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((bn.C + 15) / 16), dim3(256), 0, s, bn, 1.0 / (double)M, use_batch,
                        update_moving, eps);
     return hipGetLastError();
 }
@@ -475,7 +484,7 @@ hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
 }
 
 hipError_t p3d_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s, a, (a.mode == 2 || a.mode == 3) ? 1 : 0);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 15) / 16), dim3(256), 0, s, a, (a.mode == 2 || a.mode == 3) ? 1 : 0);
     return hipGetLastError();
 }
 
