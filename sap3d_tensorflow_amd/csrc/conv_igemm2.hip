@@ -157,12 +157,14 @@ __device__ __forceinline__ f16x4 to_half4(float4 v) { f16x4 r = {(_Float16)v.x, 
 // F16: the pointwise-conv option of BASELINE configs[4] -- operands stay fp32 in HBM and LDS, the fragments are
 // rounded to fp16 in registers and one v_mfma_f32_32x32x8_f16 (fp32 accumulate) replaces four fp32 MFMAs: a lane's
 // float4 fragment holds k = 8c + 4h + {0..3}, which is exactly the A / B operand layout of that instruction.
-template <int BM, int BN, bool WT, bool F16>
+// c-iterations [C0, C1) of one stage (BK / 8 = 4 in all): the stage is consumed in two halves so that the address
+// arithmetic and DMA issue of the next refill can run while the first half's MFMAs execute (pipe_step).
+template <int BM, int BN, bool WT, bool F16, int C0 = 0, int C1 = BK / 8>
 __device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, const float* __restrict__ b_st,
                                               f32x16 (&acc)[BM / 64][BN / 64], int wm, int wn, int h, int l31) {
     constexpr int TM = BM / 64, TN = BN / 64;
 #pragma unroll
-    for (int c = 0; c < BK / 8; ++c) {
+    for (int c = C0; c < C1; ++c) {
         float4 a[TM];
         float4 b[TN];
 #pragma unroll
@@ -225,8 +227,14 @@ __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict_
     // loads of this step have landed for this wave; with a 3-stage ring the next step's may still fly
     wait_vmcnt<(Ring<BM, BN>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();      // ... and for every wave; everyone is also done reading the stage refilled next
+#ifdef P3D_ISSUE_FIRST
     issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
     compute_stage<BM, BN, WT, F16>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
+#else
+    compute_stage<BM, BN, WT, F16, 0, BK / 16>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
+    issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
+    compute_stage<BM, BN, WT, F16, BK / 16, BK / 8>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
+#endif
 }
 
 template <int BM, int BN, bool WT, int K>

@@ -98,13 +98,15 @@ __device__ __forceinline__ void issue_stage(const WgradArgs& p, const P3dTap tap
     }
 }
 
-template <int BM, int BN>
+// rows [K0, K1) of one stage: consumed in two halves so that the next refill's address arithmetic and DMA issue run
+// while the first half's MFMAs execute (same arrangement as conv_igemm2.hip's pipe_step)
+template <int BM, int BN, int K0 = 0, int K1 = BKM>
 __device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, const float* __restrict__ b_st,
                                               f32x16 (&acc)[BM / 64][BN / 64], float& bsum, bool do_bias, int wm, int wn,
                                               int h, int l31) {
     constexpr int TM = BM / 64, TN = BN / 64;
 #pragma unroll
-    for (int k = 0; k < BKM; k += 2) {
+    for (int k = K0; k < K1; k += 2) {
         float a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i] = a_st[(k + h) * BM + wm * (BM / 2) + i * 32 + l31];
@@ -117,7 +119,7 @@ __device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, co
     }
     if (do_bias && threadIdx.x < BN) {
 #pragma unroll 8
-        for (int k = 0; k < BKM; ++k) bsum += b_st[k * BN + threadIdx.x];
+        for (int k = K0; k < K1; ++k) bsum += b_st[k * BN + threadIdx.x];
     }
 }
 
@@ -130,8 +132,9 @@ __device__ __forceinline__ void pipe_step(const WgradArgs& p, const P3dTap tap, 
     constexpr int LPS = BM / 32 + BN / 32;
     wait_vmcnt<(WRing<BM>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();
+    compute_stage<BM, BN, 0, BKM / 2>(a_src, b_src, acc, bsum, do_bias, wm, wn, lane >> 5, lane & 31);
     issue_stage<BM, BN>(p, tap, a_dst, b_dst, st, me, wave, lane);
-    compute_stage<BM, BN>(a_src, b_src, acc, bsum, do_bias, wm, wn, lane >> 5, lane & 31);
+    compute_stage<BM, BN, BKM / 2, BKM>(a_src, b_src, acc, bsum, do_bias, wm, wn, lane >> 5, lane & 31);
 }
 
 template <int BM, int BN>
