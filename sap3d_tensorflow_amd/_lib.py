@@ -78,8 +78,8 @@ def _one_rocm_runtime_per_process():
     before the library -- the order bench.py has at N > 1 anyway (torch.distributed comes first there)."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
-        return
+    if "torch" in sys.modules or os.environ.get("P3D_NO_TORCH_PRELOAD") == "1":
+        return          # (the opt-out is for processes that are known never to import torch: bench.py at N = 1, smoke())
     try:
         if importlib.util.find_spec("torch") is not None:
             import torch  # noqa: F401
