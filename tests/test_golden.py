@@ -55,3 +55,39 @@ def test_hip_reproduces_golden(name):
     assert max(errs.values()) < 6e-2, errs
     assert np.median(list(errs.values())) < 2e-2, errs
     s.close()
+
+
+STRUCTURE_OF = {"gn:p3d": "gn_p3d", "gn:decoder": "gn_p3d_decoder"}
+
+
+@pytest.mark.parametrize("name", sorted(mg.MORE))
+def test_oracle_reproduces_golden_other_graphs(name):
+    """p3d_concat, the two UNet++ heads, and the GN / CBAM nets (inference_p3d, decoder blocks)."""
+    gold = load(name)
+    out = mg.compute_more(name, np.float64)
+    assert abs(out["loss"] - gold["loss"]) <= 1e-9 * abs(gold["loss"])
+    assert sorted(out) == sorted(gold.files)
+    for k in gold.files:
+        if k != "loss":
+            assert np.array_equal(out[k], gold[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(mg.MORE))
+def test_hip_reproduces_golden_other_graphs(name):
+    from sap3d_tensorflow_amd import P3DSession
+    gold = load(name)
+    structure, cfg, params, x, y = mg.more_inputs(name)
+    B, T, H, W = mg.MORE[name][3]
+    s = P3DSession(STRUCTURE_OF.get(structure, structure), batch=B, frames=T, height=H, width=W, base=cfg.base, blocks=cfg.blocks)
+    s.load({k: v.astype(np.float32) for k, v in params.items()})
+    scale = max(np.abs(gold["pred_eval"]).max(), 1.0)
+    assert np.abs(s.forward(x, 0.0, False) - gold["pred_eval"]).max() <= 1e-3 * scale
+    loss, pt = s.backward(x, y, 0.0)
+    assert np.abs(pt - gold["pred_train"]).max() <= 1e-3 * max(np.abs(gold["pred_train"]).max(), 1.0)
+    assert abs(loss - gold["loss"]) <= 1e-5 * abs(gold["loss"])
+    errs = {k[5:]: rel_l2(s.get_grad(k[5:]), gold[k]) for k in gold.files
+            if k.startswith("grad:") and np.linalg.norm(gold[k]) > 1e-3}
+    assert errs and max(errs.values()) < 6e-2, errs
+    assert np.median(list(errs.values())) < 2e-2, errs
+    s.close()
