@@ -1,0 +1,52 @@
+// Micro-benchmark: what this MI355X sustains -- dense fp32 MFMA (v_mfma_f32_32x32x2_f32) and an HBM copy -- next to the
+// nominal peaks bench.py prices against (157.3 TFLOP/s, 8 TB/s).  hipcc --offload-arch=gfx950 -O3 peaks.hip -o peaks
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void mfma_kernel(float* out, int iters) {
+    f32x16 acc[4];
+    for (int t = 0; t < 4; ++t) for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int t = 0; t < 4; ++t) for (int e = 0; e < 16; ++e) s += acc[t][e];
+    if (s == 123.456f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void copy_kernel(const float4* src, float4* dst, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int main() {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float* out; CK(hipMalloc(&out, 16));
+    for (int wps = 1; wps <= 2; ++wps) {           // waves per SIMD: 256 CUs x 4 SIMDs x wps waves
+        const int blocks = 256 * wps, iters = 20000;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(mfma_kernel, dim3(blocks), dim3(256), 0, 0, out, iters);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double flop = (double)blocks * 4 /*waves*/ * iters * 32.0 * 4096.0;   // 32 MFMAs x 2*32*32*2 FLOP per iteration
+            printf("fp32 MFMA 32x32x2, %d wave(s)/SIMD: %.1f TFLOP/s (%.2f ms)\n", wps, flop / ms * 1e-9, ms);
+        }
+    }
+    const long long bytes = 2ll << 30;
+    float4 *src, *dst; CK(hipMalloc(&src, bytes)); CK(hipMalloc(&dst, bytes));
+    CK(hipMemset(src, 1, bytes));
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(copy_kernel, dim3(4096), dim3(256), 0, 0, src, dst, bytes / 16);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("HBM copy of %lld MiB: %.0f GB/s read+write (%.3f ms)\n", bytes >> 20, 2.0 * bytes / ms * 1e-6, ms);
+    }
+    return 0;
+}
