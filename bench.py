@@ -135,10 +135,6 @@ def main():
     ap.add_argument("--dump-launches", default=None, help="write every launch record of the profiled step to this CSV")
     args = ap.parse_args()
 
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        # single process: nothing here imports torch, so skip the shim's import-torch-first guard (a first `import torch`
-        # on a fresh box costs a minute or two of page-in)
-        os.environ.setdefault("P3D_NO_TORCH_PRELOAD", "1")
     from sap3d_tensorflow_amd.dp import Plane
     plane = Plane()
     world, rank, local_rank = plane.world, plane.rank, plane.local_rank

@@ -150,6 +150,14 @@ int p3d_profile_step(p3d_handle* h, float dropout_rate, uint64_t seed, p3d_op_ti
 #define P3D_COMM_ID_BYTES 128
 int p3d_comm_unique_id(void* id_out);
 int p3d_comm_init(p3d_handle* h, const void* id);
+/* Audit of the bucketed gradient hand-over (test hook; needs no communicator).  Runs forward + loss + backward with
+ * buckets of `bucket_floats` and, at every point where a bucket [lo, hi) of the flat gradient buffer would be handed to
+ * the all-reduce, waits for the work queued so far and copies the range out instead.  Returns the number of buckets
+ * (their ranges and the op index after whose backward each was handed over go to lo / hi / after_op, up to `cap`),
+ * *n_train = floats in the flat buffer, *stale = how many bucket elements differed from the final gradient, i.e.
+ * were handed over before their last producer had run (must be 0). */
+int p3d_debug_bucket_audit(p3d_handle* h, float dropout_rate, uint64_t seed, int64_t bucket_floats, int64_t* lo, int64_t* hi,
+                           int32_t* after_op, int cap, int64_t* n_train, int64_t* stale);
 
 /* ---- single operators on host arrays (the TF ops the path is made of), for op-level parity
  *      tests.  SAME padding, NDHWC, filters [kd,kh,kw,Cin,Cout]; strides s[3] = (sd,sh,sw). */
@@ -165,6 +173,30 @@ int p3d_op_conv3d_transpose(int device, const float* x, const int64_t xshape[5],
 int p3d_op_max_pool3d(int device, const float* x, const int64_t xshape[5], const int ksize[3], const int s[3], float* y);
 int p3d_op_max_pool3d_grad(int device, const float* x, const int64_t xshape[5], const int ksize[3], const int s[3],
                            const float* dy, float* dx);
+
+/* ---- validation metrics and frame pre-processing: the steps either side of the path.
+ *      Host arrays in and out, float64 results.  Maps are float32 [n_maps][n_pix] of ONE shape (the reference's
+ *      resize-to-match branch is not on the trainers' path).  Reference: utils/metrics.py. */
+int p3d_metric_cc(int device, const float* map1, const float* map2, int n_maps, int n_pix, double* out);    /* CC, utils/metrics.py:227-250 */
+int p3d_metric_sim(int device, const float* map1, const float* map2, int n_maps, int n_pix, double* out);   /* SIM, :258-287 */
+int p3d_metric_nss(int device, const float* sal, const float* fix, int n_maps, int n_pix, double* out);     /* NSS, :200-224; fix > 0.5 */
+/* AUC_Judd, utils/metrics.py:25-85.  jitter: the noise the reference adds (random.rand * 1e-7, :62-63) supplied by the
+ * caller, [n_maps][n_pix], or NULL for jitter=False.  NaN where a map has no fixation. */
+int p3d_metric_auc_judd(int device, const float* sal, const float* fix, const float* jitter, int n_maps, int n_pix, double* out);
+/* AUC_Borji, utils/metrics.py:88-154, one map.  rand_idx = the reference's r = random.randint(0, n_pix, [n_fix, n_rep])
+ * (:139), row-major; n_fix must equal the number of pixels with fix > 0.5.  out[n_rep] = area per random split (the
+ * reference returns their mean). */
+int p3d_metric_auc_borji(int device, const float* sal, const float* fix, const int* rand_idx, int n_pix, int n_fix, int n_rep,
+                         double step_size, double* out);
+/* mapf, dataflow.py:198-216: n decoded BGR uint8 frames [n][H0][W0][3] -> RGB - mean_rgb -> cv2.INTER_LINEAR resize to
+ * H x W -> / 255, float32 [n][H][W][3] (one clip of the NDHWC input); and the grey density maps [n][H0][W0] -> [n][H][W]. */
+int p3d_mapf_frames(int device, const unsigned char* bgr, int n, int H0, int W0, const float mean_rgb[3], int H, int W, float* out);
+int p3d_mapf_density(int device, const unsigned char* grey, int n, int H0, int W0, int H, int W, float* out);
+
+/* Releases every process-wide device resource of the library (scratch pools, the zero page) and synchronises the
+ * device; live handles must be destroyed first.  The Python shim calls it from an atexit hook so that nothing of the
+ * library is left for static destructors that may run after the HIP runtime is gone. */
+int p3d_shutdown(void);
 
 #ifdef __cplusplus
 }

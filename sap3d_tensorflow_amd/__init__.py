@@ -4,3 +4,4 @@ from ._lib import LIB_PATH, P3dError, lib        # noqa: F401
 from .session import P3DSession                  # noqa: F401
 from . import ops                                # noqa: F401
 from . import p3d, p3d_gn                        # noqa: F401  (eager mirrors of the reference's graph functions)
+from . import metrics, dataflow                  # noqa: F401  (utils/metrics.py and dataflow.py mapf on the GPU)

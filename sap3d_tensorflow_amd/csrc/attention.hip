@@ -10,6 +10,8 @@
 //   row padding of the key / value matrices to a multiple of 4 rows (N_f = 49 at 1x7x7), which keeps every
 //   GEMM operand 16-byte aligned; padded score columns are masked out of the softmax and written as 0.
 #include "p3d_kernels.h"
+#include "det_reduce.h"
+#define P3D_SEED(a) ((a).seed_dev ? *(a).seed_dev : (a).seed)   // wave-uniform; device-resident under graph replay
 
 namespace {
 
@@ -149,10 +151,10 @@ __global__ __launch_bounds__(256) void mix_fwd_kernel(AttnMixArgs a) {
         float4 z = make_float4(fmaf(r.x, gm, x.x), fmaf(r.y, gm, x.y), fmaf(r.z, gm, x.z), fmaf(r.w, gm, x.w));
         if (a.drop_scale > 0.f) {
             const long long e = row * a.C + c;
-            z.x *= u01(a.seed, e) >= a.drop_rate ? a.drop_scale : 0.f;
-            z.y *= u01(a.seed, e + 1) >= a.drop_rate ? a.drop_scale : 0.f;
-            z.z *= u01(a.seed, e + 2) >= a.drop_rate ? a.drop_scale : 0.f;
-            z.w *= u01(a.seed, e + 3) >= a.drop_rate ? a.drop_scale : 0.f;
+            z.x *= u01(P3D_SEED(a), e) >= a.drop_rate ? a.drop_scale : 0.f;
+            z.y *= u01(P3D_SEED(a), e + 1) >= a.drop_rate ? a.drop_scale : 0.f;
+            z.z *= u01(P3D_SEED(a), e + 2) >= a.drop_rate ? a.drop_scale : 0.f;
+            z.w *= u01(P3D_SEED(a), e + 3) >= a.drop_rate ? a.drop_scale : 0.f;
         }
         st4(a.z + row * a.ldz + c, z);
     }
@@ -171,10 +173,10 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(AttnMixArgs a) {
         float4 dz = ld4(a.dz + row * a.ldz + c);
         if (a.drop_scale > 0.f) {
             const long long e = row * a.C + c;
-            dz.x *= u01(a.seed, e) >= a.drop_rate ? a.drop_scale : 0.f;
-            dz.y *= u01(a.seed, e + 1) >= a.drop_rate ? a.drop_scale : 0.f;
-            dz.z *= u01(a.seed, e + 2) >= a.drop_rate ? a.drop_scale : 0.f;
-            dz.w *= u01(a.seed, e + 3) >= a.drop_rate ? a.drop_scale : 0.f;
+            dz.x *= u01(P3D_SEED(a), e) >= a.drop_rate ? a.drop_scale : 0.f;
+            dz.y *= u01(P3D_SEED(a), e + 1) >= a.drop_rate ? a.drop_scale : 0.f;
+            dz.z *= u01(P3D_SEED(a), e + 2) >= a.drop_rate ? a.drop_scale : 0.f;
+            dz.w *= u01(P3D_SEED(a), e + 3) >= a.drop_rate ? a.drop_scale : 0.f;
         }
         const float4 r = ld4(a.r + row * a.ldr + c);
         acc += dz.x * r.x + dz.y * r.y + dz.z * r.z + dz.w * r.w;
@@ -187,7 +189,18 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(AttnMixArgs a) {
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(a.dgamma, (red[0] + red[1]) + (red[2] + red[3]));
+    // per-block partial; the last arriving block adds them in block order (no atomics)
+    __shared__ int last_flag;
+    if (threadIdx.x == 0) a.part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (!p3d_last_block(a.counter, gridDim.x, &last_flag)) return;
+    float t = 0.f;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += a.part[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) a.dgamma[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // dst[b][0..Npad) x C  <-  src[b][0..N) x C, rows N..Npad zero  (add = 1: src[b][r] += dst... the reverse, for gradients)
@@ -238,7 +251,11 @@ hipError_t p3d_attn_mix_fwd(const AttnMixArgs& a, hipStream_t s) {
 
 hipError_t p3d_attn_mix_bwd(const AttnMixArgs& a, hipStream_t s) {
     if ((a.C & 3) || (a.ldr & 3) || (a.ldx & 3) || (a.ldz & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mix_bwd_kernel, dim3(capped((a.M * (a.C >> 2) + 255) / 256, 2048)), dim3(256), 0, s, a);
+    const unsigned g = capped((a.M * (a.C >> 2) + 255) / 256, 2048);
+    AttnMixArgs aa = a;
+    const hipError_t e = p3d_stream_scratch(s, g, 1, &aa.part, &aa.counter);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3(g), dim3(256), 0, s, aa);
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 // vectors.  reduce_max gradients are split equally between tied maxima (TF's _MinOrMaxGrad), which matters here
 // because x is post-ReLU and whole channels / positions can be zero.
 #include "p3d_kernels.h"
+#include "det_reduce.h"
 
 namespace {
 
@@ -223,7 +224,16 @@ __global__ __launch_bounds__(384) void bwd_k7_kernel(CbamArgs a) {
             }
         }
     }
-    if (tap < 343) { unsafeAtomicAdd(a.dk7 + tap * 2, a0); unsafeAtomicAdd(a.dk7 + tap * 2 + 1, a1); }
+    // per-block partials; the last arriving block adds them in block order (no atomics)
+    __shared__ int last_flag;
+    if (tap < 343) { a.k7part[((size_t)blockIdx.x * 343 + tap) * 2] = a0; a.k7part[((size_t)blockIdx.x * 343 + tap) * 2 + 1] = a1; }
+    if (!p3d_last_block(a.k7counter, gridDim.x, &last_flag)) return;
+    if (tap < 343) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll 4
+        for (unsigned b = 0; b < gridDim.x; ++b) { t0 += a.k7part[((size_t)b * 343 + tap) * 2]; t1 += a.k7part[((size_t)b * 343 + tap) * 2 + 1]; }
+        a.dk7[tap * 2] += t0; a.dk7[tap * 2 + 1] += t1;
+    }
 }
 
 // grid (chunks, N), wave per position inside the chunk: df = dout*ss + dmean/C + dmax*[f == max]/ties;
@@ -387,7 +397,13 @@ hipError_t p3d_cbam_backward(const CbamArgs& a, hipStream_t s) {
     const long long M = (long long)a.N * a.D * a.H * a.W;
     hipLaunchKernelGGL(bwd_dpre_kernel, dim3(capped((M + 3) / 4, 8192)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bwd_spat_conv_kernel, dim3(capped((M + 255) / 256, 4096)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(bwd_k7_kernel, dim3(capped((M + 63) / 64, 1024)), dim3(384), 0, s, a);
+    {
+        const unsigned g7 = capped((M + 63) / 64, 256);      // the last arriver folds g7 partials: keep that tail short
+        CbamArgs a7 = a;
+        const hipError_t e7 = p3d_stream_scratch(s, (size_t)g7 * 343 * 2, 1, &a7.k7part, &a7.k7counter);
+        if (e7 != hipSuccess) return e7;
+        hipLaunchKernelGGL(bwd_k7_kernel, dim3(g7), dim3(384), 0, s, a7);
+    }
     hipLaunchKernelGGL(bwd_df_kernel, dim3(a.chunks, a.N), dim3(256), 4 * a.C * sizeof(float), s, a);
     hipLaunchKernelGGL(bwd_mlp1_kernel, dim3((a.Ch + 7) / 8, a.N), dim3(256), a.C * sizeof(float), s, a);
     hipLaunchKernelGGL(bwd_mlp2a_kernel, dim3((a.N * a.C + 255) / 256), dim3(256), 0, s, a);

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             }
         }
     }
-    if (p.stats) {
+    if (p.statpart) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             s1[j] += __shfl_xor(s1[j], 32);
@@ -243,9 +243,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         }
         __syncthreads();
         if (tid < BN && (n0 + tid) < p.Nc) {
-            double* st = p.stats + (size_t)(blockIdx.x % P3D_STAT_REPLICAS) * 2 * p.Nc;
-            unsafeAtomicAdd(&st[2 * (n0 + tid) + 0], (double)(sred[0][tid][0] + sred[1][tid][0]));
-            unsafeAtomicAdd(&st[2 * (n0 + tid) + 1], (double)(sred[0][tid][1] + sred[1][tid][1]));
+            float* st = p.statpart + ((size_t)(p.stat_base + mt) * p.Nc + n0 + tid) * 2;      // per-tile partial, plain stores
+            st[0] = sred[0][tid][0] + sred[1][tid][0];
+            st[1] = sred[0][tid][1] + sred[1][tid][1];
         }
     }
 }

@@ -10,19 +10,24 @@
 //    stored at chunk q ^ ((r >> 1) & 7): conflict-free for the 32x32x2 A/B fragment reads);
 //  * rows that fall into SAME padding, and channel tails, read from a zero page instead of
 //    branching, so every wave issues the same number of loads per step (the vmcnt count);
-//  * split-K: gridDim.y slices the (tap, k-chunk) step range so that layers with few output
-//    tiles (M = B*98 positions in stage 3) still cover 256 CUs; partial tiles are combined with
-//    fp32 global atomics into a pre-zeroed output (bias rides on slice 0).
+//  * K-slicing: layers with few output tiles (M = B*98 positions in stage 3) cut the (tap, k-chunk) step
+//    range into slices so that they still cover 256 CUs.  Every slice stores its partial tile to a scratch
+//    slab and takes an arrival ticket; the block that draws the last ticket sums the slabs IN SLICE ORDER and
+//    writes the output (bias, accumulate and BatchNorm statistics included), so results are bit-reproducible --
+//    fp32 atomics were not (cdna_hip_programming.md, "Projection GEMM at M = 256", item 2);
 //
 // fp32 in / fp32 accumulate: v_mfma_f32_32x32x2_f32, exact fp32 at the fp32 peak (157 TFLOP/s).
 #include "p3d_kernels.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -159,65 +164,79 @@ __device__ __forceinline__ f16x4 to_half4(float4 v) { f16x4 r = {(_Float16)v.x, 
 // float4 fragment holds k = 8c + 4h + {0..3}, which is exactly the A / B operand layout of that instruction.
 // c-iterations [C0, C1) of one stage (BK / 8 = 4 in all): the stage is consumed in two halves so that the address
 // arithmetic and DMA issue of the next refill can run while the first half's MFMAs execute (pipe_step).
-template <int BM, int BN, bool WT, bool F16, int C0 = 0, int C1 = BK / 8>
-__device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, const float* __restrict__ b_st,
-                                              f32x16 (&acc)[BM / 64][BN / 64], int wm, int wn, int h, int l31) {
+// Fragments of one whole stage (BK / 8 = 4 c-iterations): every ds_read of the step is issued BEFORE the first MFMA, so
+// the LDS latency is paid once per step instead of once per c-iteration (each 32x32x2 MFMA chain on one accumulator is
+// 4 x 64 cycles: with the reads interleaved the matrix pipe idled ~120 cycles in every 256).
+template <int BM, int BN, bool WT>
+struct Frags {
+    float4 a[BK / 8][BM / 64];
+    float4 b[BK / 8][BN / 64];
+};
+template <int BM, int BN, bool WT>
+__device__ __forceinline__ void load_frags(const float* __restrict__ a_st, const float* __restrict__ b_st, Frags<BM, BN, WT>& f,
+                                           int wm, int wn, int h, int l31) {
     constexpr int TM = BM / 64, TN = BN / 64;
 #pragma unroll
-    for (int c = C0; c < C1; ++c) {
-        float4 a[TM];
-        float4 b[TN];
+    for (int c = 0; c < BK / 8; ++c) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int r = wm * (BM / 2) + i * 32 + l31;
             const int slot = (2 * c + h) ^ ((r >> 1) & 7);
-            a[i] = *reinterpret_cast<const float4*>(a_st + r * BK + slot * 4);
+            f.a[c][i] = *reinterpret_cast<const float4*>(a_st + r * BK + slot * 4);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * (BN / 2) + j * 32 + l31;
             if (WT) {
                 const int slot = (2 * c + h) ^ ((col >> 1) & 7);
-                b[j] = *reinterpret_cast<const float4*>(b_st + col * BK + slot * 4);
+                f.b[c][j] = *reinterpret_cast<const float4*>(b_st + col * BK + slot * 4);
             } else {
                 const float* bp = b_st + (c * 8 + 4 * h) * BN + col;
-                b[j] = make_float4(bp[0], bp[BN], bp[2 * BN], bp[3 * BN]);
+                f.b[c][j] = make_float4(bp[0], bp[BN], bp[2 * BN], bp[3 * BN]);
             }
         }
-#ifdef P3D_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
+    }
+}
+
+// F16: the pointwise-conv option of BASELINE configs[4] -- operands stay fp32 in HBM and LDS, the fragments are
+// rounded to fp16 in registers and one v_mfma_f32_32x32x8_f16 (fp32 accumulate) replaces four fp32 MFMAs: a lane's
+// float4 fragment holds k = 8c + 4h + {0..3}, which is exactly the A / B operand layout of that instruction.
+// c-iterations [C0, C1) of one stage: the stage is consumed in two halves so that the address arithmetic and DMA issue
+// of the next refill can run while the first half's MFMAs execute (pipe_step).
+template <int BM, int BN, bool WT, bool F16, int C0, int C1>
+__device__ __forceinline__ void mfma_frags(const Frags<BM, BN, WT>& f, f32x16 (&acc)[BM / 64][BN / 64]) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+#pragma unroll
+    for (int c = C0; c < C1; ++c) {
         if constexpr (F16) {
             f16x4 ah[TM], bh[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) ah[i] = to_half4(a[i]);
+            for (int i = 0; i < TM; ++i) ah[i] = to_half4(f.a[c][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bh[j] = to_half4(b[j]);
+            for (int j = 0; j < TN; ++j) bh[j] = to_half4(f.b[c][j]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float av = s == 0 ? a[i].x : s == 1 ? a[i].y : s == 2 ? a[i].z : a[i].w;
+                for (int i = 0; i < TM; ++i) {
+                    const float av = s == 0 ? f.a[c][i].x : s == 1 ? f.a[c][i].y : s == 2 ? f.a[c][i].z : f.a[c][i].w;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float bv = s == 0 ? b[j].x : s == 1 ? b[j].y : s == 2 ? b[j].z : b[j].w;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        const float bv = s == 0 ? f.b[c][j].x : s == 1 ? f.b[c][j].y : s == 2 ? f.b[c][j].z : f.b[c][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
                 }
-            }
         }
-#ifdef P3D_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     }
 }
 
 // One pipeline step with COMPILE-TIME stage addresses and restrict-qualified views of the ring.
-// Branch-free: wait for this step's loads, barrier, issue step+2, compute.
+// Branch-free: wait for this step's loads, barrier, read the stage's fragments, first half of the MFMAs, issue step+2,
+// second half.
 template <int BM, int BN, bool WT, bool F16>
 __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict__ a_dst, float* __restrict__ b_dst,
                                           const float* __restrict__ a_src, const float* __restrict__ b_src,
@@ -227,13 +246,20 @@ __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict_
     // loads of this step have landed for this wave; with a 3-stage ring the next step's may still fly
     wait_vmcnt<(Ring<BM, BN>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();      // ... and for every wave; everyone is also done reading the stage refilled next
-#ifdef P3D_ISSUE_FIRST
+    Frags<BM, BN, WT> f;
+    load_frags<BM, BN, WT>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
+    __builtin_amdgcn_sched_barrier(0);      // keep every read above the MFMAs (hipcc otherwise sinks half of them back)
+#if defined(P3D_TUNE_NO_MFMA)               // tools/micro only: what does a step cost without the matrix work / without the DMA
+    acc[0][0][0] += f.a[0][0].x * f.b[0][0].x + f.a[BK / 8 - 1][0].w * f.b[BK / 8 - 1][0].w;
     issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
-    compute_stage<BM, BN, WT, F16>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
+#elif defined(P3D_TUNE_NO_DMA)
+    mfma_frags<BM, BN, WT, F16, 0, BK / 16>(f, acc);
+    ++st.issued; if (++st.kc == kchunks) { st.kc = 0; ++st.t; }
+    mfma_frags<BM, BN, WT, F16, BK / 16, BK / 8>(f, acc);
 #else
-    compute_stage<BM, BN, WT, F16, 0, BK / 16>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
+    mfma_frags<BM, BN, WT, F16, 0, BK / 16>(f, acc);
     issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
-    compute_stage<BM, BN, WT, F16, BK / 16, BK / 8>(a_src, b_src, acc, wm, wn, lane >> 5, lane & 31);
+    mfma_frags<BM, BN, WT, F16, BK / 16, BK / 8>(f, acc);
 #endif
 }
 
@@ -287,8 +313,15 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
 
     const long long M = (long long)p.N * p.Gd * p.Gh * p.Gw;
     const int NT = (p.Nc + BN - 1) / BN;
-    const int nt = blockIdx.x % NT;
-    const long long m0 = (long long)(blockIdx.x / NT) * BM;
+    const int nsplit = p.nsplit;
+    // block -> (output tile, K-slice).  xmap: consecutive blocks are the slices of one tile, so with round-robin
+    // dispatch over the 8 XCDs slice s of every tile lands on XCD s (mod 8) and the A rows / weight slabs of a slice
+    // are fetched into one L2 once instead of eight times.  Placement is a speed matter only.
+    const int tile_id = p.xmap ? (int)(blockIdx.x / nsplit) : (int)blockIdx.x;
+    const int slice = p.xmap ? (int)(blockIdx.x - (unsigned)tile_id * nsplit) : (int)blockIdx.y;
+    const int nt = tile_id % NT;
+    const int mt = tile_id / NT;
+    const long long m0 = (long long)mt * BM;
     const int n0 = nt * BN;
 
     const unsigned Mu = (unsigned)M, m0u = (unsigned)m0;      // launcher guarantees M < 2^31
@@ -308,11 +341,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     // ---- this block's slice of the (tap, k-chunk) steps --------------------------------------------
     const int kchunks = (p.K + BK - 1) / BK;
     const int total_steps = p.ntaps * kchunks;
-    const int nsplit = gridDim.y;
     const int per = (total_steps + nsplit - 1) / nsplit;
-    const int s_begin = blockIdx.y * per;
+    const int s_begin = slice * per;
     const int s_end = min(total_steps, s_begin + per);
-    const int nsteps = (p.exp == 1) ? 0 : max(s_end - s_begin, 0);
+    const int nsteps = max(s_end - s_begin, 0);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -329,56 +361,18 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     PrologueLoop<BM, BN, WT, 0>::run(p, As, Bs, st, nsteps, kchunks, wave, lane);
     for (int base = 0; base < nsteps; base += STAGES)
         StepLoop<BM, BN, WT, F16, 0>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn);
-    __syncthreads();      // rowOut written above is read below (also when nsteps == 0)
 
     // ---- epilogue ----------------------------------------------------------------------------------
-    if (p.exp == 2) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
-    if (nsplit > 1) {
-        // split-K: partial tile straight from the accumulators; one wave-instruction = two 128-B row segments
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + l31;
-            const bool cok = col < p.Nc;
-            const float bv = (p.bias && cok && blockIdx.y == 0) ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int r = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const long long ro = rowOut[r];
-                    if (ro >= 0 && cok) unsafeAtomicAdd(p.y + ro + col, acc[i][j][e] + bv);
-                }
-        }
-        return;
-    }
-    // whole-K: stage the tile through LDS (the ring is free once the tail DMA has landed) so that global
-    // traffic is row-wise float4 -- bias, optional accumulate (batched loads instead of 64 dependent dword
-    // read-modify-writes per lane) and the per-channel statistics all come from the staged tile.
+    // Stage the tile through LDS (the ring is free once the tail DMA has landed) so that global traffic is row-wise
+    // float4 -- bias, optional accumulate (batched loads instead of 64 dependent dword read-modify-writes per lane)
+    // and the per-channel statistics all come from the staged tile.
     constexpr int LDT = BN + 4;
+    constexpr int F4R = BN / 4;
     float* tile = As;
+    float* sred = tile + BM * LDT;                              // [4][BN][2] statistics exchange
+    int* flag = reinterpret_cast<int*>(sred + 4 * BN * 2);      // "this block reduces the slices" (same LDS array: no second object)
     wait_vmcnt<0>();
-    __syncthreads();
-    if (p.stats) {
-        // per-channel (sum, sumsq) of the stored values straight from the accumulators: lane = column, the 16*TM
-        // registers = rows; fold the two lane halves with a shuffle and the two wave rows through LDS (after the tile).
-        float* sred = tile + BM * LDT;                          // [2][BN][2]
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int lc = wn * (BN / 2) + j * 32 + l31;
-            const float bv = (p.bias && (n0 + lc) < p.Nc) ? p.bias[n0 + lc] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int r = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (rowOut[r] >= 0) { const float v = acc[i][j][e] + bv; s1 += v; s2 += v * v; }
-                }
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (h == 0) { sred[(wm * BN + lc) * 2] = s1; sred[(wm * BN + lc) * 2 + 1] = s2; }
-        }
-    }
+    __syncthreads();                                            // also orders rowOut (written above) before its readers
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -389,7 +383,83 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
                 tile[r * LDT + wn * (BN / 2) + j * 32 + l31] = acc[i][j][e];
             }
     __syncthreads();
-    constexpr int F4R = BN / 4;
+
+    if (nsplit > 1) {
+        // -- partial tile -> slab, arrival ticket; the last arriver folds the slabs back into the LDS tile ----------
+        // Slab stores are WRITE-THROUGH (sc1): they need no release fence (whose L2 write-back costs 2-6 us per block);
+        // every storing wave drains its stores, the block meets at a barrier, one lane takes the ticket
+        // (cdna_hip_programming.md Guideline 16, recipe R1).
+        float* myslab = p.slab + ((size_t)tile_id * nsplit + slice) * (BM * BN);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(myslab, 0, BM * BN * 4, 0x00020000);
+#pragma unroll 4
+        for (int i = tid; i < BM * F4R; i += 256) {
+            const int r = i / F4R, c4 = (i - r * F4R) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
+            const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, (r * BN + c4) * 4, 0, 16);      // aux 16 = sc1
+        }
+        wait_vmcnt<0>();                                        // every storing wave drains its stores ...
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(p.cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == (unsigned)(nsplit - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale lines before the plain slab loads
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                p.cnt[tile_id] = 0;                             // ready for the next launch that uses this scratch
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        const float* slabs = p.slab + (size_t)tile_id * nsplit * (BM * BN);
+        // The slabs come from other CUs' write-through stores: every load is a long-latency miss, so keep 16 of them in
+        // flight per lane (4 tile positions x 4 slices) and add in slice order.
+        constexpr int PER_LANE = BM * F4R / 256;                // float4 positions per lane: 4 / 8 / 16
+        static_assert(PER_LANE % 4 == 0, "reducer unrolls four tile positions");
+#pragma unroll 1
+        for (int i0 = 0; i0 < PER_LANE; i0 += 4) {
+            float4 v[4];
+            const float* src[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + (i0 + q) * 256;
+                const int r = i / F4R, c4 = (i - r * F4R) * 4;
+                src[q] = slabs + r * BN + c4;
+                v[q] = *reinterpret_cast<const float4*>(src[q]);
+            }
+            int sidx = 1;
+            for (; sidx + 3 < nsplit; sidx += 4) {
+                float4 a[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[t][q] = *reinterpret_cast<const float4*>(src[q] + (size_t)(sidx + t) * (BM * BN));
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q].x += a[t][q].x; v[q].y += a[t][q].y; v[q].z += a[t][q].z; v[q].w += a[t][q].w; }
+            }
+            for (; sidx < nsplit; ++sidx) {
+                float4 a[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const float4*>(src[q] + (size_t)sidx * (BM * BN));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q].x += a[q].x; v[q].y += a[q].y; v[q].z += a[q].z; v[q].w += a[q].w; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + (i0 + q) * 256;
+                const int r = i / F4R, c4 = (i - r * F4R) * 4;
+                *reinterpret_cast<float4*>(tile + r * LDT + c4) = v[q];
+            }
+        }
+        __syncthreads();
+    }
+
+    // -- output rows: bias, optional accumulate, row-wise float4 stores; the stored values go back to the tile for the
+    //    statistics pass --------------------------------------------------------------------------------------------
+    const bool want_stats = p.statpart != nullptr;
 #pragma unroll 4
     for (int i = tid; i < BM * F4R; i += 256) {
         const int r = i / F4R, c4 = (i - r * F4R) * 4;
@@ -398,44 +468,62 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
         if (ro < 0 || col >= p.Nc) continue;
         float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
         if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (want_stats) *reinterpret_cast<float4*>(tile + r * LDT + c4) = v;
         float* dst = p.y + ro + col;
         if (p.accum) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *reinterpret_cast<float4*>(dst) = v;
     }
-    if (p.stats && tid < BN && (n0 + tid) < p.Nc) {
-        const float* sred = tile + BM * LDT;
-        double* st = p.stats + (size_t)(blockIdx.x % P3D_STAT_REPLICAS) * 2 * p.Nc;
-        unsafeAtomicAdd(&st[2 * (n0 + tid) + 0], (double)(sred[tid * 2] + sred[(BN + tid) * 2]));
-        unsafeAtomicAdd(&st[2 * (n0 + tid) + 1], (double)(sred[tid * 2 + 1] + sred[(BN + tid) * 2 + 1]));
+    if (want_stats) {
+        // per-channel (sum, sumsq) over this tile's valid rows: 4 row groups x BN columns, folded in a fixed order
+        __syncthreads();
+        constexpr int RG = 256 / BN, RPG = BM / RG;
+        const int col = tid % BN, rg = tid / BN;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+        for (int r = rg * RPG; r < (rg + 1) * RPG; ++r)
+            if (rowOut[r] >= 0) { const float v = tile[r * LDT + col]; s1 += v; s2 = fmaf(v, v, s2); }
+        sred[(rg * BN + col) * 2] = s1; sred[(rg * BN + col) * 2 + 1] = s2;
+        __syncthreads();
+        if (tid < BN && (n0 + tid) < p.Nc) {
+            float t1 = sred[tid * 2], t2 = sred[tid * 2 + 1];
+#pragma unroll
+            for (int g = 1; g < RG; ++g) { t1 += sred[(g * BN + tid) * 2]; t2 += sred[(g * BN + tid) * 2 + 1]; }
+            float* dst = p.statpart + ((size_t)(p.stat_base + mt) * p.Nc + n0 + tid) * 2;
+            dst[0] = t1; dst[1] = t2;
+        }
     }
 }
 
 template <int BM, int BN>
 constexpr size_t smem_bytes() {
     const size_t ring = (size_t)Ring<BM, BN>::stages * (BM * BK + BK * BN) * 4;
-    const size_t tile = (size_t)BM * (BN + 4) * 4 + 2 * BN * 2 * 4;       // staged tile + statistics exchange
+    const size_t tile = (size_t)BM * (BN + 4) * 4 + 4 * BN * 2 * 4 + 16;   // staged tile + statistics exchange + reducer flag
     return BM * 8 + (ring > tile ? ring : tile);
 }
 
 template <int BM, int BN>
-hipError_t launch_t(const IgemmArgs& a, int splits, hipStream_t s) {
+hipError_t launch_t(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) {
+    IgemmArgs a = a0;
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const long long tiles = ((M + BM - 1) / BM) * ((a.Nc + BN - 1) / BN);
-    dim3 grid((unsigned)tiles, (unsigned)splits);
+    const int splits = pl.splits < 1 ? 1 : pl.splits;
+    a.nsplit = splits; a.xmap = (splits > 1 && pl.xmap) ? 1 : 0;
+    a.slab = nullptr; a.cnt = nullptr;
+    if (splits > 1) {
+        const hipError_t e = p3d_stream_scratch(s, (size_t)tiles * splits * BM * BN, (size_t)tiles, &a.slab, &a.cnt);
+        if (e != hipSuccess) return e;
+    }
+    const dim3 grid = a.xmap ? dim3((unsigned)(tiles * splits)) : dim3((unsigned)tiles, (unsigned)splits);
     constexpr size_t sm = smem_bytes<BM, BN>();
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         attr_done = true;
     }
     if (a.f16) {
-        static bool attr16_done = false;
-        if (!attr16_done) {
-            hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-            hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-            attr16_done = true;
-        }
         if (a.wT) hipLaunchKernelGGL((igemm2_kernel<BM, BN, true, true>), grid, dim3(256), sm, s, a);
         else      hipLaunchKernelGGL((igemm2_kernel<BM, BN, false, true>), grid, dim3(256), sm, s, a);
         return hipGetLastError();
@@ -445,38 +533,74 @@ hipError_t launch_t(const IgemmArgs& a, int splits, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- per-stream scratch (partial tiles + arrival counters) -----------------------------------------------------
+struct Scratch { float* slab = nullptr; size_t slab_floats = 0; unsigned* cnt = nullptr; size_t counters = 0; };
+std::vector<void*> g_scratch_allocs;       // every buffer ever handed out (outgrown ones stay valid until shutdown)
+std::map<hipStream_t, Scratch> g_scratch;
+std::mutex g_scratch_mutex;
+
 }  // namespace
 
-// Tile / split choice.  Prefer the biggest tile (least LDS traffic per FLOP) that still yields
-// enough blocks; then slice K until ~2 blocks per CU exist.  Splitting needs a zeroed output and
-// cannot carry the statistics epilogue or accumulate mode, so the caller must allow it.
-int p3d_igemm2_exp() { static const int v = getenv("P3D_EXP") ? atoi(getenv("P3D_EXP")) : 0; return v; }
+hipError_t p3d_stream_scratch(hipStream_t s, size_t slab_floats, size_t counters, float** slab, unsigned** cnt) {
+    std::lock_guard<std::mutex> g(g_scratch_mutex);
+    Scratch& sc = g_scratch[s];
+    if (slab_floats > sc.slab_floats) {
+        // grow with headroom; the outgrown buffer is deliberately not freed (a captured graph may still name it)
+        const size_t want = slab_floats + slab_floats / 2 + (1u << 20);
+        float* p = nullptr;
+        const hipError_t e = hipMalloc((void**)&p, want * sizeof(float));
+        if (e != hipSuccess) return e;
+        sc.slab = p; sc.slab_floats = want; g_scratch_allocs.push_back(p);
+    }
+    if (counters > sc.counters) {
+        const size_t want = counters * 2 + 4096;
+        unsigned* p = nullptr;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(unsigned));
+        if (e != hipSuccess) return e;
+        e = hipMemset(p, 0, want * sizeof(unsigned));        // tickets start at zero; every reducer re-zeroes its own
+        if (e != hipSuccess) return e;
+        sc.cnt = p; sc.counters = want; g_scratch_allocs.push_back(p);
+    }
+    *slab = sc.slab; *cnt = sc.cnt;
+    return hipSuccess;
+}
+
+void p3d_release_scratch() {
+    std::lock_guard<std::mutex> g(g_scratch_mutex);
+    for (void* p : g_scratch_allocs) hipFree(p);
+    g_scratch_allocs.clear();
+    g_scratch.clear();
+}
 
 namespace {
 
-// ---- plan cache + on-device autotuning -------------------------------------------------------------------------
-// The best (tile, K-slices) pair depends on how the launch quantises over 256 CUs, on LDS-DMA fill versus MFMA time
-// and on the price of combining partial tiles with atomics; a cost model gets within ~10 %, measuring gets it right.
-// With P3D_TUNE=1, during graph build (p3d_create) the first request for a shape times every candidate on the real
-// buffers (3 runs each, minimum) and caches the winner for the life of the process.  Off by default: on the
-// reference shapes the measured winners are within ~1 % of the heuristic below (same step time), and a fixed
-// launch configuration keeps split-K summation orders -- hence results -- stable from run to run.
-struct PlanKey {
-    long long M; int K, Nc, ntaps, wT, allow, epi;
-    bool operator<(const PlanKey& o) const {
-        return std::tie(M, K, Nc, ntaps, wT, allow, epi) < std::tie(o.M, o.K, o.Nc, o.ntaps, o.wT, o.allow, o.epi);
-    }
-};
-std::map<PlanKey, P3dIgemmPlan> g_plans;
-std::mutex g_plan_mutex;
-hipStream_t g_tune_stream = nullptr;
-bool g_tuning = false;
-
+// ---- plan: tile and K-slices per launch ------------------------------------------------------------------------
+// Big layers take the biggest tile that still yields enough blocks (least LDS traffic per FLOP).  Layers with few
+// output tiles cut K into slices: wall time is about one block's latency until blocks exceed the 256 CUs, so the
+// slice count aims at 0.75-1x the CU count, never 2x (cdna_hip_programming.md, "Projection GEMM at M = 256", item 1),
+// and is a divisor pattern of 8 so that xmap can give each XCD one slice.  Every plan is numerically valid; plans
+// differ only in speed and in the (fixed, per-plan) summation order of the K-slices.
 const char* plan_name(int bm, int bn) {
     return bm == 128 ? (bn == 128 ? "igemm2_kernel<128,128>" : "igemm2_kernel<128,64>") : "igemm2_kernel<64,64>";
 }
 
-P3dIgemmPlan heuristic_plan(const IgemmArgs& a, int allow_split) {
+struct PlanOverride { int tile = -1, splits = 0, xmap = -1; };
+PlanOverride g_override;
+std::once_flag g_override_once;
+std::mutex g_plan_mutex;
+
+void read_override_env() {
+    // Tuning sweeps only (tools/): force the tile, the K-slice count or the block mapping.  Read once; a forced value
+    // that a shape cannot take is ignored for that shape.
+    if (const char* e = getenv("P3D_TILE")) g_override.tile = atoi(e);
+    if (const char* e = getenv("P3D_SPLITS")) g_override.splits = atoi(e);
+    if (const char* e = getenv("P3D_XMAP")) g_override.xmap = atoi(e);
+    if (g_override.tile >= 0 || g_override.splits > 0 || g_override.xmap >= 0)
+        fprintf(stderr, "[p3d] WARNING: igemm2 plan override in effect (P3D_TILE=%d P3D_SPLITS=%d P3D_XMAP=%d): tuning only\n",
+                g_override.tile, g_override.splits, g_override.xmap);
+}
+
+P3dIgemmPlan heuristic_plan(const IgemmArgs& a) {
     P3dIgemmPlan pl;
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const int kchunks = (a.K + BK - 1) / BK;
@@ -486,94 +610,57 @@ P3dIgemmPlan heuristic_plan(const IgemmArgs& a, int allow_split) {
     if (a.Nc > 64 && tiles(128, 128) >= want) { pl.bm = 128; pl.bn = 128; }
     else if (tiles(128, 64) >= want || (a.Nc <= 64 && tiles(128, 64) >= 128)) { pl.bm = 128; pl.bn = 64; }
     else { pl.bm = 64; pl.bn = 64; }
-    pl.splits = 1;
-    if (allow_split && steps >= 8) {
-        const long long t = tiles(pl.bm, pl.bn);
-        if (t < 150) {
-            long long s = (300 + t / 2) / t;
-            const long long smax = steps / 6 > 0 ? steps / 6 : 1;
-            if (s > smax) s = smax;
-            if (s < 1) s = 1;
-            pl.splits = (int)s;
+    pl.splits = 1; pl.xmap = 0;
+    const long long t = tiles(pl.bm, pl.bn);
+    if (pl.bm == 64 && pl.bn == 64 && t < 150 && steps >= 8) {
+        // Measured on MI355X (tools/micro/conv_chain.hip, M = 784 rows, cold weights): a 64x64 step costs ~0.78 us while
+        // at most one block sits on a CU and proportionally more beyond that; cutting K into s slices costs ~3 + 0.4 s us
+        // (write-through slab stores, ticket, the last arriver's s slab reads, 16 loads in flight per lane).  Pick the
+        // power of two that minimises the sum; more than 8 slices never paid.
+        double best_cost = 1e30;
+        for (int sp = 1; sp <= 8; sp *= 2) {
+            if (sp > 1 && steps / sp < 3) break;
+            const double per_block = (double)((steps + sp - 1) / sp) * 0.78 * std::max(1.0, (double)(t * sp) / 256.0);
+            const double cost = per_block + (sp > 1 ? 3.0 + 0.4 * sp : 0.0);
+            if (cost < best_cost) { best_cost = cost; pl.splits = sp; }
         }
     }
     pl.name = plan_name(pl.bm, pl.bn);
     return pl;
-}
-
-hipError_t launch_plan(const IgemmArgs& a, const P3dIgemmPlan& pl, hipStream_t s);
-
-P3dIgemmPlan measure_plan(const IgemmArgs& a0, int allow_split) {
-    const int kchunks = (a0.K + BK - 1) / BK;
-    const int steps = a0.ntaps * kchunks;
-    const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    P3dIgemmPlan best = heuristic_plan(a0, allow_split);
-    float best_ms = 1e30f;
-    for (auto& t : tiles) {
-        if (t[1] == 128 && a0.Nc <= 64) continue;
-        for (int sp : splits) {
-            if (sp > 1 && (!allow_split || sp > steps / 2)) break;
-            P3dIgemmPlan pl; pl.bm = t[0]; pl.bn = t[1]; pl.splits = sp; pl.name = plan_name(t[0], t[1]);
-            IgemmArgs a = a0;
-            if (sp > 1) { a.stats = nullptr; a.accum = 0; }
-            float ms_min = 1e30f;
-            bool ok = true;
-            for (int rep = 0; rep < 4 && ok; ++rep) {
-                hipEventRecord(e0, g_tune_stream);
-                ok = launch_plan(a, pl, g_tune_stream) == hipSuccess;
-                hipEventRecord(e1, g_tune_stream);
-                if (hipEventSynchronize(e1) != hipSuccess) ok = false;
-                float ms = 0;
-                hipEventElapsedTime(&ms, e0, e1);
-                if (rep > 0 && ms < ms_min) ms_min = ms;
-            }
-            if (ok && ms_min < best_ms * 0.97f) { best_ms = ms_min; best = pl; }
-        }
-    }
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    return best;
 }
 
 }  // namespace
 
-void p3d_tune_begin(hipStream_t s) { std::lock_guard<std::mutex> g(g_plan_mutex); g_tune_stream = s; g_tuning = getenv("P3D_TUNE") != nullptr && atoi(getenv("P3D_TUNE")) != 0; }
-void p3d_tune_end() { std::lock_guard<std::mutex> g(g_plan_mutex); g_tuning = false; }
-
-// Tile / K-slice choice for one launch.  Slicing needs a zeroed output and cannot carry the statistics epilogue
-// or accumulate mode, so the caller must allow it.
-P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split) {
-    const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
-    const PlanKey key{M, a.K, a.Nc, a.ntaps, a.wT, allow_split ? 1 : 0, (a.stats ? 1 : 0) | (a.accum ? 2 : 0) | (a.bias ? 4 : 0)};
+void p3d_tune_begin(hipStream_t) {}
+void p3d_tune_end() {}
+void p3d_igemm2_override(int tile, int splits, int xmap) {      // tools/micro only
+    std::call_once(g_override_once, read_override_env);
     std::lock_guard<std::mutex> g(g_plan_mutex);
-    auto it = g_plans.find(key);
-    if (it != g_plans.end()) return it->second;
-    P3dIgemmPlan pl = heuristic_plan(a, allow_split);
-    if (g_tuning && a.x && a.y && a.w && a.zeros && a.ntaps > 0 && M > 0) {
-        pl = measure_plan(a, allow_split);
-        g_plans[key] = pl;
-    }
+    g_override.tile = tile; g_override.splits = splits; g_override.xmap = xmap;
+}
+
+// Tile / K-slice choice for one launch.
+P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int) {
+    std::call_once(g_override_once, read_override_env);
+    P3dIgemmPlan pl = heuristic_plan(a);
+    PlanOverride ov;
+    { std::lock_guard<std::mutex> g(g_plan_mutex); ov = g_override; }
     const int steps = a.ntaps * ((a.K + BK - 1) / BK);
-    if (const char* e = getenv("P3D_SPLITS")) {            // tuning override (tools/tune_igemm.py)
-        const int v = atoi(e);
-        if (v >= 1 && allow_split && v <= steps) pl.splits = v;
-    }
-    if (const char* e = getenv("P3D_TILE")) {
-        const int v = atoi(e);
-        if (v == 0) { pl.bm = 64; pl.bn = 64; } else if (v == 1) { pl.bm = 128; pl.bn = 64; } else if (v == 2) { pl.bm = 128; pl.bn = 128; }
-    }
+    if (ov.tile == 0) { pl.bm = 64; pl.bn = 64; }
+    else if (ov.tile == 1) { pl.bm = 128; pl.bn = 64; }
+    else if (ov.tile == 2 && a.Nc > 64) { pl.bm = 128; pl.bn = 128; }
+    if (ov.splits >= 1 && ov.splits <= steps) { pl.splits = ov.splits; if (pl.splits == 1) pl.xmap = 0; }
+    if (ov.xmap >= 0) pl.xmap = (ov.xmap && pl.splits > 1) ? 1 : 0;
     pl.name = plan_name(pl.bm, pl.bn);
     return pl;
 }
 
+namespace { hipError_t launch_plan(const IgemmArgs& a, const P3dIgemmPlan& pl, hipStream_t s); }
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& pl, hipStream_t s) { return launch_plan(a, pl, s); }
 
 namespace {
 hipError_t launch_plan(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) {
     IgemmArgs a = a0;
-    a.exp = p3d_igemm2_exp();
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     if (M <= 0 || a.Nc <= 0) return hipSuccess;
     if (M >= (1ll << 31) || (long long)a.N * a.Di * a.Hi * a.Wi >= (1ll << 31)) return hipErrorInvalidValue;
@@ -581,9 +668,9 @@ hipError_t launch_plan(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t 
     if (a.ntaps > P3D_MAX_TAPS || a.stem_wfloats) return hipErrorInvalidValue;
     if ((a.K & 3) || (a.ldx & 3) || !a.zeros) return hipErrorInvalidValue;
     if ((a.Nc & 3) || (a.ldy & 3)) return hipErrorInvalidValue;
-    if (pl.splits > 1 && (a.accum || a.stats)) return hipErrorInvalidValue;
-    if (pl.bm == 128 && pl.bn == 128) return launch_t<128, 128>(a, pl.splits, s);
-    if (pl.bm == 128 && pl.bn == 64) return launch_t<128, 64>(a, pl.splits, s);
-    return launch_t<64, 64>(a, pl.splits, s);
+    if (pl.splits > 1 && pl.splits > a.ntaps * ((a.K + BK - 1) / BK)) return hipErrorInvalidValue;
+    if (pl.bm == 128 && pl.bn == 128) return launch_t<128, 128>(a, pl, s);
+    if (pl.bm == 128 && pl.bn == 64) return launch_t<128, 64>(a, pl, s);
+    return launch_t<64, 64>(a, pl, s);
 }
 }  // namespace

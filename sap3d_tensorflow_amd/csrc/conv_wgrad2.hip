@@ -3,12 +3,24 @@
 // with the machinery of conv_igemm2.hip): both operands are [position][channel] rows exactly as
 // they lie in NDHWC memory, streamed global -> LDS by LDS-DMA into a 3-stage ring (one raw
 // s_barrier + one counted vmcnt per 32-position step), consumed by v_mfma_f32_32x32x2_f32 with
-// k = position.  Padded / out-of-range rows come from a zero page.  The position range is split
-// over gridDim.y; partial tiles are added with fp32 atomics (dW is zeroed once per step).
+// k = position.  Padded / out-of-range rows come from a zero page.
+//
+// GROUPED: one launch carries up to P3D_WGRAD_GROUP independent problems (the filter gradients of one
+// bottleneck: 1x1x1 reduce, 1x3x3, 3x1x1, 1x1x1 expand -- tf.gradients of p3d.py:86-125).  Stage 3 has
+// only 784 positions to reduce over, so one problem offers 48-144 output tiles; four together fill the
+// 256 CUs without cutting the position range, i.e. without any cross-block sum.
+//
+// DETERMINISTIC: where the position range IS cut (big tensors, few filter tiles), every cut stores its
+// partial tile to a scratch slab and takes an arrival ticket; the block with the last ticket adds the
+// slabs in cut order and updates dW (and the bias gradient) with plain read-modify-writes.  No float
+// atomics anywhere: two runs give bit-identical gradients.
 #include "p3d_kernels.h"
 #include <algorithm>
+#include <cstring>
+#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -25,6 +37,27 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// One problem of a group, as the kernel sees it (kernel-argument space: keep it compact).
+struct WProb {
+    const float* x; const float* dy; float* dw; float* dbias;
+    int N, Di, Hi, Wi, ldx, K;
+    int Gd, Gh, Gw, isd, ish, isw;
+    int ldy, Nc;
+    int ksplit;          // cuts of the position range
+    int blk0;            // first block of this problem in the launch's 1-D grid
+    int tile0;           // first (tile) slot of this problem in the scratch slabs / counters
+    int ntaps;
+    signed char tap[P3D_MAX_TAPS][4];      // dd, dh, dw, weight slab
+};
+struct WGroup {
+    int nprob;
+    const float* zeros;
+    float* slab; unsigned* cnt;
+    int kstride;         // slab index of (slot, cut) = slot * kstride + cut
+    WProb p[P3D_WGRAD_GROUP];
+};
+static_assert(sizeof(WGroup) <= 3800, "kernel arguments must stay under the 4 KB kernarg segment");
+
 // Per-lane loader state in registers: the lattice coordinates of the rows this lane fetches, advanced
 // by 32 positions per step with small-integer reciprocal carries (no per-step division).
 template <int LA, int LB>
@@ -39,7 +72,7 @@ struct WState {
 };
 
 template <int BM, int BN>
-__device__ __forceinline__ void wloader_init(const WgradArgs& p, WState<BM / 32, BN / 32>& st, unsigned ms, int k0, int n0,
+__device__ __forceinline__ void wloader_init(const WProb& p, WState<BM / 32, BN / 32>& st, unsigned ms, int k0, int n0,
                                              int wave, int lane) {
     constexpr int LA = BM / 32, LB = BN / 32;
     constexpr int A_LPR = BM / 4, A_RPP = 64 / A_LPR, B_LPR = BN / 4, B_RPP = 64 / B_LPR;
@@ -64,14 +97,14 @@ __device__ __forceinline__ void wloader_init(const WgradArgs& p, WState<BM / 32,
 
 // Always LA + LB loads (rows past the slice end, padded rows and channel tails read the zero page).
 template <int BM, int BN>
-__device__ __forceinline__ void issue_stage(const WgradArgs& p, const P3dTap tap, float* __restrict__ a_dst,
+__device__ __forceinline__ void issue_stage(const WProb& p, const float* zeros, int tdd, int tdh, int tdw, float* __restrict__ a_dst,
                                             float* __restrict__ b_dst, WState<BM / 32, BN / 32>& st, unsigned me, int wave,
                                             int lane) {
     constexpr int LA = BM / 32, LB = BN / 32;
-    const float* zp = p.zeros + 4 * (lane & 7);
+    const float* zp = zeros + 4 * (lane & 7);
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int id = st.gd[i] * p.isd + tap.dd, ih = st.gh[i] * p.ish + tap.dh, iw = st.gw[i] * p.isw + tap.dw;
+        const int id = st.gd[i] * p.isd + tdd, ih = st.gh[i] * p.ish + tdh, iw = st.gw[i] * p.isw + tdw;
         const bool ok = st.m[i] < me && st.kc[i] < p.K && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
                         (unsigned)iw < (unsigned)p.Wi;
         const float* src = ok ? p.x + ((((long long)st.n[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw) * p.ldx + st.kc[i] : zp;
@@ -98,33 +131,44 @@ __device__ __forceinline__ void issue_stage(const WgradArgs& p, const P3dTap tap
     }
 }
 
-// rows [K0, K1) of one stage: consumed in two halves so that the next refill's address arithmetic and DMA issue run
-// while the first half's MFMAs execute (same arrangement as conv_igemm2.hip's pipe_step)
-template <int BM, int BN, int K0 = 0, int K1 = BKM>
-__device__ __forceinline__ void compute_stage(const float* __restrict__ a_st, const float* __restrict__ b_st,
-                                              f32x16 (&acc)[BM / 64][BN / 64], float& bsum, bool do_bias, int wm, int wn,
-                                              int h, int l31) {
+// All fragment reads of a stage are issued before its first MFMA (one exposed LDS latency per step instead of one per
+// pair of MFMAs); the stage is then consumed in two halves so that the next refill's address arithmetic and DMA issue
+// run while the first half's MFMAs execute (same arrangement as conv_igemm2.hip's pipe_step).
+template <int BM, int BN>
+struct WFrags { float a[BKM / 2][BM / 64]; float b[BKM / 2][BN / 64]; };
+
+template <int BM, int BN>
+__device__ __forceinline__ void load_wfrags(const float* __restrict__ a_st, const float* __restrict__ b_st, WFrags<BM, BN>& f,
+                                            int wm, int wn, int h, int l31) {
     constexpr int TM = BM / 64, TN = BN / 64;
 #pragma unroll
-    for (int k = K0; k < K1; k += 2) {
-        float a[TM], b[TN];
+    for (int k2 = 0; k2 < BKM / 2; ++k2) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = a_st[(k + h) * BM + wm * (BM / 2) + i * 32 + l31];
+        for (int i = 0; i < TM; ++i) f.a[k2][i] = a_st[(2 * k2 + h) * BM + wm * (BM / 2) + i * 32 + l31];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = b_st[(k + h) * BN + wn * (BN / 2) + j * 32 + l31];
+        for (int j = 0; j < TN; ++j) f.b[k2][j] = b_st[(2 * k2 + h) * BN + wn * (BN / 2) + j * 32 + l31];
+    }
+}
+template <int BM, int BN, int K0, int K1>
+__device__ __forceinline__ void mfma_wfrags(const WFrags<BM, BN>& f, f32x16 (&acc)[BM / 64][BN / 64]) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+#pragma unroll
+    for (int k2 = K0 / 2; k2 < K1 / 2; ++k2)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[k2][i], f.b[k2][j], acc[i][j], 0, 0, 0);
+}
+template <int BN>
+__device__ __forceinline__ void bias_rows(const float* __restrict__ b_st, float& bsum, bool do_bias) {
     if (do_bias && threadIdx.x < BN) {
 #pragma unroll 8
-        for (int k = K0; k < K1; ++k) bsum += b_st[k * BN + threadIdx.x];
+        for (int k = 0; k < BKM; ++k) bsum += b_st[k * BN + threadIdx.x];
     }
 }
 
 template <int BM, int BN>
-__device__ __forceinline__ void pipe_step(const WgradArgs& p, const P3dTap tap, float* __restrict__ a_dst,
+__device__ __forceinline__ void pipe_step(const WProb& p, const float* zeros, int tdd, int tdh, int tdw, float* __restrict__ a_dst,
                                           float* __restrict__ b_dst, const float* __restrict__ a_src,
                                           const float* __restrict__ b_src, f32x16 (&acc)[BM / 64][BN / 64], float& bsum,
                                           bool do_bias, WState<BM / 32, BN / 32>& st, unsigned me, int wave, int lane, int wm,
@@ -132,13 +176,24 @@ __device__ __forceinline__ void pipe_step(const WgradArgs& p, const P3dTap tap, 
     constexpr int LPS = BM / 32 + BN / 32;
     wait_vmcnt<(WRing<BM>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();
-    compute_stage<BM, BN, 0, BKM / 2>(a_src, b_src, acc, bsum, do_bias, wm, wn, lane >> 5, lane & 31);
-    issue_stage<BM, BN>(p, tap, a_dst, b_dst, st, me, wave, lane);
-    compute_stage<BM, BN, BKM / 2, BKM>(a_src, b_src, acc, bsum, do_bias, wm, wn, lane >> 5, lane & 31);
+    WFrags<BM, BN> f;
+    load_wfrags<BM, BN>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
+    __builtin_amdgcn_sched_barrier(0);      // keep every read above the MFMAs (hipcc otherwise sinks them back, pair by pair)
+    mfma_wfrags<BM, BN, 0, BKM / 2>(f, acc);
+    issue_stage<BM, BN>(p, zeros, tdd, tdh, tdw, a_dst, b_dst, st, me, wave, lane);
+    mfma_wfrags<BM, BN, BKM / 2, BKM>(f, acc);
+    bias_rows<BN>(b_src, bsum, do_bias);
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void wgrad2_kernel(const WgradArgs p) {
+constexpr size_t wsmem_bytes() {
+    const size_t ring = (size_t)WRing<BM>::stages * BKM * (BM + BN) * 4;
+    const size_t tile = (size_t)BM * (BN + 4) * 4 + BN * 4 + 16;      // staged tile + bias sums + reducer flag
+    return ring > tile ? ring : tile;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_STAGE = BKM * BM, B_STAGE = BKM * BN;
     constexpr int STAGES = WRing<BM>::stages;
@@ -152,18 +207,38 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WgradArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
+    // which problem of the group does this block belong to (block ranges are ascending)
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < P3D_WGRAD_GROUP; ++q)
+        if (q < g.nprob && (int)blockIdx.x >= g.p[q].blk0) pi = q;
+    // copy the problem out of the kernel-argument segment once: a reference indexed by `pi` makes hipcc re-load its
+    // fields (s_load + wait) inside the pipeline loop
+    WProb p;
+    {
+        const WProb& src = g.p[pi];
+        p.x = src.x; p.dy = src.dy; p.dw = src.dw; p.dbias = src.dbias;
+        p.N = src.N; p.Di = src.Di; p.Hi = src.Hi; p.Wi = src.Wi; p.ldx = src.ldx; p.K = src.K;
+        p.Gd = src.Gd; p.Gh = src.Gh; p.Gw = src.Gw; p.isd = src.isd; p.ish = src.ish; p.isw = src.isw;
+        p.ldy = src.ldy; p.Nc = src.Nc; p.ksplit = src.ksplit; p.blk0 = src.blk0; p.tile0 = src.tile0; p.ntaps = src.ntaps;
+    }
+
     const long long M = (long long)p.N * p.Gd * p.Gh * p.Gw;
     const int KT = (p.K + BM - 1) / BM, NT = (p.Nc + BN - 1) / BN;
-    int b = blockIdx.x;
+    // consecutive blocks are the cuts of one tile: with 8 cuts, cut c of every tile shares XCD c's L2 (speed only)
+    const int local = (int)blockIdx.x - p.blk0;
+    const int tile_local = local / p.ksplit;
+    const int cut = local - tile_local * p.ksplit;
+    int b = tile_local;
     const int nt = b % NT; b /= NT;
     const int kt = b % KT;
     const int ti = b / KT;
-    const P3dTap tap = p.taps[ti];
+    const int tdd = g.p[pi].tap[ti][0], tdh = g.p[pi].tap[ti][1], tdw = g.p[pi].tap[ti][2], widx = g.p[pi].tap[ti][3];
     const int k0 = kt * BM, n0 = nt * BN;
 
     long long chunk = (M + p.ksplit - 1) / p.ksplit;
     chunk = (chunk + BKM - 1) / BKM * BKM;
-    const long long ms = (long long)blockIdx.y * chunk;
+    const long long ms = (long long)cut * chunk;
     const long long me = (ms + chunk < M) ? ms + chunk : M;
     const int nsteps = me > ms ? (int)((me - ms + BKM - 1) / BKM) : 0;
 
@@ -183,57 +258,122 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WgradArgs p) {
     if (STAGES == 3) {
         float* A0 = As; float* A1 = As + A_STAGE; float* A2 = As + 2 * A_STAGE;
         float* B0 = Bs; float* B1 = Bs + B_STAGE; float* B2 = Bs + 2 * B_STAGE;
-        issue_stage<BM, BN>(p, tap, A0, B0, st, meu, wave, lane);
-        issue_stage<BM, BN>(p, tap, A1, B1, st, meu, wave, lane);
+        issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, st, meu, wave, lane);
+        issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, st, meu, wave, lane);
         for (int base = 0; base < nsteps; base += 3) {
-            pipe_step<BM, BN>(p, tap, A2, B2, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
-            if (base + 1 < nsteps) pipe_step<BM, BN>(p, tap, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
-            if (base + 2 < nsteps) pipe_step<BM, BN>(p, tap, A1, B1, A2, B2, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A2, B2, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            if (base + 1 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            if (base + 2 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, A2, B2, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
         }
     } else {
         float* A0 = As; float* A1 = As + A_STAGE;
         float* B0 = Bs; float* B1 = Bs + B_STAGE;
-        issue_stage<BM, BN>(p, tap, A0, B0, st, meu, wave, lane);
+        issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, st, meu, wave, lane);
         for (int base = 0; base < nsteps; base += 2) {
-            pipe_step<BM, BN>(p, tap, A1, B1, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
-            if (base + 1 < nsteps) pipe_step<BM, BN>(p, tap, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            if (base + 1 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
         }
     }
-    __syncthreads();
 
-    float* dwt = p.dw + (long long)tap.widx * p.K * p.Nc;
+    // ---- epilogue: stage the tile through LDS (row-wise float4 global traffic) -----------------------------------
+    constexpr int LDT = BN + 4, F4R = BN / 4;
+    float* tile = As;
+    float* bias_lds = tile + BM * LDT;                           // [BN]
+    int* flag = reinterpret_cast<int*>(bias_lds + BN);
+    wait_vmcnt<0>();
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = k0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < p.K && col < p.Nc) unsafeAtomicAdd(&dwt[(long long)row * p.Nc + col], acc[i][j][e]);
+                const int r = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                tile[r * LDT + wn * (BN / 2) + j * 32 + l31] = acc[i][j][e];
             }
-        }
-    if (do_bias && tid < BN && (n0 + tid) < p.Nc) unsafeAtomicAdd(&p.dbias[n0 + tid], bsum);
-}
+    if (tid < BN) bias_lds[tid] = bsum;
+    __syncthreads();
 
-template <int BM, int BN>
-hipError_t launch_t(const WgradArgs& a, long long tiles, hipStream_t s) {
-    constexpr size_t sm = (size_t)WRing<BM>::stages * BKM * (BM + BN) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)wgrad2_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        attr_done = true;
+    if (p.ksplit > 1) {
+        constexpr int SLAB = BM * BN + BN;                       // tile + bias partial
+        const int slot = p.tile0 + tile_local;
+        // write-through (sc1) slab stores: no release fence needed (conv_igemm2.hip; Guideline 16 recipe R1)
+        float* myslab = g.slab + ((size_t)slot * g.kstride + cut) * SLAB;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(myslab, 0, SLAB * 4, 0x00020000);
+#pragma unroll 4
+        for (int i = tid; i < BM * F4R; i += 256) {
+            const int r = i / F4R, c4 = (i - r * F4R) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
+            const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, (r * BN + c4) * 4, 0, 16);
+        }
+        if (tid < BN) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bias_lds[tid]), rs, (BM * BN + tid) * 4, 0, 16);
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(g.cnt + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == (unsigned)(p.ksplit - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                g.cnt[slot] = 0;
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        const float* slabs = g.slab + (size_t)slot * g.kstride * SLAB;
+#pragma unroll 2
+        for (int i = tid; i < BM * F4R; i += 256) {
+            const int r = i / F4R, c4 = (i - r * F4R) * 4;
+            const float* src = slabs + r * BN + c4;
+            float4 v = *reinterpret_cast<const float4*>(src);
+            int s = 1;
+            for (; s + 3 < p.ksplit; s += 4) {                  // four loads in flight, added in cut order
+                const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)(s + 0) * SLAB);
+                const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)(s + 1) * SLAB);
+                const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)(s + 2) * SLAB);
+                const float4 a3 = *reinterpret_cast<const float4*>(src + (size_t)(s + 3) * SLAB);
+                v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
+                v.x += a1.x; v.y += a1.y; v.z += a1.z; v.w += a1.w;
+                v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w;
+                v.x += a3.x; v.y += a3.y; v.z += a3.z; v.w += a3.w;
+            }
+            for (; s < p.ksplit; ++s) {
+                const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * SLAB);
+                v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
+            }
+            *reinterpret_cast<float4*>(tile + r * LDT + c4) = v;
+        }
+        if (tid < BN) {
+            float t = 0.f;
+            for (int s = 0; s < p.ksplit; ++s) t += slabs[(size_t)s * SLAB + BM * BN + tid];
+            bias_lds[tid] = t;
+        }
+        __syncthreads();
     }
-    hipLaunchKernelGGL((wgrad2_kernel<BM, BN>), dim3((unsigned)tiles, (unsigned)a.ksplit), dim3(256), sm, s, a);
-    return hipGetLastError();
+
+    float* dwt = p.dw + (long long)widx * p.K * p.Nc;
+#pragma unroll 4
+    for (int i = tid; i < BM * F4R; i += 256) {
+        const int r = i / F4R, c4 = (i - r * F4R) * 4;
+        const int row = k0 + r, col = n0 + c4;
+        if (row >= p.K || col >= p.Nc) continue;
+        float* dst = dwt + (long long)row * p.Nc + col;
+        float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
+        const float4 o = *reinterpret_cast<const float4*>(dst);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        *reinterpret_cast<float4*>(dst) = v;
+    }
+    if (do_bias && tid < BN && (n0 + tid) < p.Nc) p.dbias[n0 + tid] += bias_lds[tid];
 }
 
 struct WPlan { int tile; long long tiles; int ks; double cost; };
-// Pick the tile and the number of position-range splits with a small cost model: blocks run in rounds of
+// Pick the tile and the number of position-range cuts with a small cost model: blocks run in rounds of
 // `slots` (256 CUs x resident blocks per CU), a round lasts (steps per block + fixed overhead) step-times, and a
 // 128x128 step is ~3.2x a 64x64 step (4x the MFMAs, better LDS-DMA efficiency).  This avoids e.g. 540 blocks on
-// 512 slots (a second round with 28 blocks).
-WPlan plan(const WgradArgs& a) {
+// 512 slots (a second round with 28 blocks).  `other_tiles`: 64x64 tiles of the other problems in the same launch.
+WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const long long steps = (M + BKM - 1) / BKM;
     auto best_for = [&](int T) {
@@ -241,37 +381,109 @@ WPlan plan(const WgradArgs& a) {
         w.tile = T; w.ks = 1; w.cost = 1e300;
         w.tiles = (long long)a.ntaps * ((a.K + T - 1) / T) * ((a.Nc + T - 1) / T);
         const long long slots = 256 * (T == 128 ? 2 : 3);
-        const double step_time = T == 128 ? 3.2 : 1.0, overhead = T == 128 ? 8.0 : 8.0;
-        const long long kmax = std::max<long long>(1, std::min<long long>(steps / 4, 4096));
+        const double step_time = T == 128 ? 3.2 : 1.0, overhead = 8.0;
+        const long long kmax = std::max<long long>(1, std::min<long long>(steps / 4, 64));
         for (long long ks = 1; ks <= kmax; ks = ks < 16 ? ks + 1 : ks + ks / 8) {
-            const long long blocks = w.tiles * ks;
+            const long long blocks = (w.tiles + other_tiles) * ks;
             const long long rounds = (blocks + slots - 1) / slots;
-            const double per_block = (double)((steps + ks - 1) / ks) + overhead;
+            // a cut costs its slab store, and the last arriver reads ks slabs
+            const double per_block = (double)((steps + ks - 1) / ks) + overhead + (ks > 1 ? 2.0 + 0.5 * ks : 0.0);
             const double cost = rounds * per_block * step_time;
-            if (cost < w.cost * 0.98) { w.cost = cost; w.ks = (int)std::min<long long>(ks, 65535); }
+            if (cost < w.cost * 0.98) { w.cost = cost; w.ks = (int)ks; }
         }
         return w;
     };
     const WPlan small = best_for(64);
-    if (a.K >= 128 && a.Nc >= 128) {
+    if (other_tiles == 0 && a.K >= 128 && a.Nc >= 128) {
         const WPlan big = best_for(128);
         if (big.cost <= small.cost) return big;
     }
     return small;
 }
 
+bool wgrad_ok(const WgradArgs& a) {
+    const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
+    if (M >= (1ll << 31) - 4096 || a.Gw > 400 || a.Gh > 400 || a.Gd > 400) return false;   // reciprocal carries
+    if (a.ntaps > P3D_MAX_TAPS || a.stem_wfloats || !a.zeros) return false;
+    if ((a.K & 3) || (a.ldx & 3) || (a.Nc & 3) || (a.ldy & 3)) return false;
+    for (int t = 0; t < a.ntaps; ++t)
+        if (a.taps[t].dd < -128 || a.taps[t].dd > 127 || a.taps[t].dh < -128 || a.taps[t].dh > 127 || a.taps[t].dw < -128 ||
+            a.taps[t].dw > 127 || a.taps[t].widx < 0 || a.taps[t].widx > 127)
+            return false;
+    return true;
+}
+
+void fill_prob(WProb& p, const WgradArgs& a) {
+    p.x = a.x; p.dy = a.dy; p.dw = a.dw; p.dbias = a.dbias;
+    p.N = a.N; p.Di = a.Di; p.Hi = a.Hi; p.Wi = a.Wi; p.ldx = a.ldx; p.K = a.K;
+    p.Gd = a.Gd; p.Gh = a.Gh; p.Gw = a.Gw; p.isd = a.isd; p.ish = a.ish; p.isw = a.isw;
+    p.ldy = a.ldy; p.Nc = a.Nc; p.ntaps = a.ntaps;
+    for (int t = 0; t < a.ntaps; ++t) {
+        p.tap[t][0] = (signed char)a.taps[t].dd; p.tap[t][1] = (signed char)a.taps[t].dh;
+        p.tap[t][2] = (signed char)a.taps[t].dw; p.tap[t][3] = (signed char)a.taps[t].widx;
+    }
+}
+
+template <int BM, int BN>
+hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slots, hipStream_t s) {
+    constexpr size_t sm = wsmem_bytes<BM, BN>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)wgrad2_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        attr_done = true;
+    }
+    g.slab = nullptr; g.cnt = nullptr;
+    if (slabs > 0) {
+        const hipError_t e = p3d_stream_scratch(s, (size_t)slabs * (BM * BN + BN), (size_t)slots, &g.slab, &g.cnt);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((wgrad2_kernel<BM, BN>), dim3((unsigned)blocks), dim3(256), sm, s, g);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 const char* p3d_wgrad2_variant(const WgradArgs& a) { return plan(a).tile == 128 ? "wgrad2_kernel<128,128>" : "wgrad2_kernel<64,64>"; }
 
-hipError_t p3d_launch_wgrad2(const WgradArgs& a0, hipStream_t s) {
-    WgradArgs a = a0;
-    const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
-    if (M <= 0 || a.ntaps <= 0) return hipSuccess;
-    if (M >= (1ll << 31) - 4096 || a.Gw > 400 || a.Gh > 400 || a.Gd > 400) return hipErrorInvalidValue;   // reciprocal carries
-    if (a.ntaps > P3D_MAX_TAPS || a.stem_wfloats || !a.zeros) return hipErrorInvalidValue;
-    if ((a.K & 3) || (a.ldx & 3) || (a.Nc & 3) || (a.ldy & 3)) return hipErrorInvalidValue;
-    const WPlan w = plan(a);
-    a.ksplit = w.ks;
-    return w.tile == 128 ? launch_t<128, 128>(a, w.tiles, s) : launch_t<64, 64>(a, w.tiles, s);
+// One launch for up to P3D_WGRAD_GROUP problems.  A single problem may take the 128x128 tile; groups use 64x64.
+hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s) {
+    std::vector<const WgradArgs*> live;
+    for (int i = 0; i < n; ++i) {
+        const WgradArgs& a = probs[i];
+        const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
+        if (M <= 0 || a.ntaps <= 0) continue;
+        if (!wgrad_ok(a)) return hipErrorInvalidValue;
+        live.push_back(&a);
+    }
+    if (live.empty()) return hipSuccess;
+    if ((int)live.size() > P3D_WGRAD_GROUP) return hipErrorInvalidValue;
+    WGroup g;
+    memset(&g, 0, sizeof(g));
+    g.nprob = (int)live.size();
+    g.zeros = live[0]->zeros;
+    const int tile = live.size() == 1 ? plan(*live[0]).tile : 64;
+    long long tiles64_all = 0;
+    for (auto* a : live) tiles64_all += (long long)a->ntaps * ((a->K + 63) / 64) * ((a->Nc + 63) / 64);
+    long long blocks = 0;
+    int tile0 = 0, kstride = 1;
+    for (size_t q = 0; q < live.size(); ++q) {
+        const WgradArgs& a = *live[q];
+        WProb& p = g.p[q];
+        fill_prob(p, a);
+        const long long my64 = (long long)a.ntaps * ((a.K + 63) / 64) * ((a.Nc + 63) / 64);
+        const WPlan w = live.size() == 1 ? plan(a) : plan(a, tiles64_all - my64);
+        const long long tiles = (long long)a.ntaps * ((a.K + tile - 1) / tile) * ((a.Nc + tile - 1) / tile);
+        p.ksplit = w.ks;
+        p.blk0 = (int)blocks;
+        p.tile0 = tile0;
+        blocks += tiles * p.ksplit;
+        tile0 += (int)tiles;
+        kstride = std::max(kstride, p.ksplit);
+    }
+    g.kstride = kstride;       // slab of (slot, cut) = slot * kstride + cut: disjoint whatever each problem's cut count
+    if (blocks >= (1ll << 31)) return hipErrorInvalidValue;
+    const long long slabs = kstride > 1 ? (long long)tile0 * kstride : 0;
+    return tile == 128 ? launch_group_t<128, 128>(g, blocks, slabs, tile0, s) : launch_group_t<64, 64>(g, blocks, slabs, tile0, s);
 }
+
+hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s) { return p3d_launch_wgrad2_group(&a, 1, s); }

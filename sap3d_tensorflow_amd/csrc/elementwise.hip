@@ -4,6 +4,8 @@
 // place on channel slices of the decoder's concat buffers (tf.concat at reference
 // p3d.py:203,208 never materialises).
 #include "p3d_kernels.h"
+#include "det_reduce.h"
+#define P3D_SEED(a) ((a).seed_dev ? *(a).seed_dev : (a).seed)   // wave-uniform; device-resident under graph replay
 
 namespace {
 
@@ -35,22 +37,34 @@ __device__ __forceinline__ float4 dropmask4(unsigned long long seed, long long e
 }
 
 // ------------------------------------------------------------------------------------------------
-// 16 lanes per channel: lane r loads replica r, the 16 are folded with shuffles (one load latency instead of a chain
-// of 16); lane 0 of the group finishes the channel.  These tiny kernels sit on the critical path ~100 times per step.
+// Folds of 16 replicas / partials with shuffles (one load latency instead of a chain of 16); lane 0 of the group
+// finishes the channel.  These tiny kernels sit on the critical path ~100 times per step.
 static_assert(P3D_STAT_REPLICAS == 16, "finalize kernels fold 16 replicas with 4 shuffle steps");
 __device__ __forceinline__ double fold16(double v) {
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// BatchNorm finalize.  LPC lanes per channel (16 or 64): lane r adds partials r, r + LPC, ... in double, in that order,
+// then the lanes are folded by a fixed shuffle tree -- the statistics are bit-reproducible (the partials are plain
+// stores of the producer's epilogue, not atomics).
+template <int LPC>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(BnParams bn, double invM, int use_batch, int update_moving, float eps) {
-    const int r = threadIdx.x & 15;
-    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int r = threadIdx.x % LPC;
+    const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     const bool ok = c < bn.C;
     double s1 = 0.0, s2 = 0.0;
     if (use_batch) {
-        if (ok) { s1 = bn.stats[(size_t)r * 2 * bn.C + 2 * c]; s2 = bn.stats[(size_t)r * 2 * bn.C + 2 * c + 1]; }
-        s1 = fold16(s1); s2 = fold16(s2);
+        if (ok) {
+            const float2* part = reinterpret_cast<const float2*>(bn.statpart) + c;
+#pragma unroll 4
+            for (int q = r; q < bn.nparts; q += LPC) {
+                const float2 v = part[(size_t)q * bn.C];
+                s1 += (double)v.x; s2 += (double)v.y;
+            }
+        }
+#pragma unroll
+        for (int o = LPC / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     }
     if (!ok || r) return;
     double mean, var;
@@ -74,8 +88,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnParams bn, double in
     bn.invstd[c] = (float)inv;
 }
 
-// Per-channel (sum, sumsq) of y.  Thread = one float4 channel group, RPI rows per block pass.
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int ld, long long M, int C, double* stats) {
+// Per-channel (sum, sumsq) of y.  Thread = one float4 channel group, RPI rows per block pass.  Block b writes partial b.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int ld, long long M, int C, float* statpart) {
     __shared__ float red[256][8];
     const int c4n = C >> 2;
     const int rpi = 256 / c4n;
@@ -100,12 +114,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int ld, l
         for (int s = 0; s < rpi; ++s)
 #pragma unroll
             for (int q = 0; q < 8; ++q) t[q] += red[s * c4n + tid][q];
-        double* st = stats + (size_t)(blockIdx.x % P3D_STAT_REPLICAS) * 2 * C;
+        float* st = statpart + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsafeAtomicAdd(&st[2 * (c + q) + 0], (double)t[q]);
-            unsafeAtomicAdd(&st[2 * (c + q) + 1], (double)t[4 + q]);
-        }
+        for (int q = 0; q < 4; ++q) { st[2 * (c + q) + 0] = t[q]; st[2 * (c + q) + 1] = t[4 + q]; }
     }
 }
 
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
         else if (MODE == 2) z = relu4(add4(v, fma4(ld4(a.scale2 + c), ld4(a.y2 + row * a.ld2 + c), ld4(a.shift2 + c))));
         else if (MODE == 3) z = add4(relu4(v), relu4(fma4(ld4(a.scale2 + c), ld4(a.y2 + row * a.ld2 + c), ld4(a.shift2 + c))));
         else z = add4(ld4(a.y2 + row * a.ld2 + c), relu4(v));
-        if (a.drop_scale > 0.f) z = mul4(z, dropmask4(a.seed, row * a.C + c, a.drop_rate, a.drop_scale));
+        if (a.drop_scale > 0.f) z = mul4(z, dropmask4(P3D_SEED(a), row * a.C + c, a.drop_rate, a.drop_scale));
         st4(a.z + row * a.ldz + c, z);
     }
 }
@@ -134,7 +145,7 @@ template <int MODE>
 __device__ __forceinline__ void bn_bwd_gates(const BnBwdArgs& a, long long row, int c, float4& g1, float4& g2,
                                              float4& y1, float4& y2) {
     float4 dz = ld4(a.dz + row * a.lddz + c);
-    if (a.drop_scale > 0.f) dz = mul4(dz, dropmask4(a.seed, row * a.C + c, a.drop_rate, a.drop_scale));
+    if (a.drop_scale > 0.f) dz = mul4(dz, dropmask4(P3D_SEED(a), row * a.C + c, a.drop_rate, a.drop_scale));
     y1 = ld4(a.y1 + row * a.ld1 + c);
     const float4 v1 = fma4(ld4(a.scale1 + c), y1, ld4(a.shift1 + c));
     y2 = f4(0.f);
@@ -191,21 +202,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
         for (int s = 0; s < rpi; ++s)
 #pragma unroll
             for (int q = 0; q < NV; ++q) t[q] += red[s * c4n + tid][q];
-        const size_t rep = (size_t)(blockIdx.x % P3D_STAT_REPLICAS) * 2 * a.C;
+        // block b's partial sums, plain stores (bit-reproducible; folded in block order by bn_bwd_finalize)
+        float* p1 = a.part1 + ((size_t)blockIdx.x * a.C + c) * 2;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsafeAtomicAdd(&a.red1[rep + 2 * (c + q) + 0], (double)t[q]);
-            unsafeAtomicAdd(&a.red1[rep + 2 * (c + q) + 1], (double)t[4 + q]);
-            if (TWO) {
-                unsafeAtomicAdd(&a.red2[rep + 2 * (c + q) + 0], (double)t[8 + q]);
-                unsafeAtomicAdd(&a.red2[rep + 2 * (c + q) + 1], (double)t[12 + q]);
-            }
+        for (int q = 0; q < 4; ++q) { p1[2 * q] = t[q]; p1[2 * q + 1] = t[4 + q]; }
+        if (TWO) {
+            float* p2 = a.part2 + ((size_t)blockIdx.x * a.C + c) * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { p2[2 * q] = t[8 + q]; p2[2 * q + 1] = t[12 + q]; }
         }
     }
 }
 
-// Folds the replicated sums: coef[c] = (sum g / M, sum g*xhat / M) and the BN parameter gradients
-// (each BN parameter is produced exactly once per step, so they are written, not accumulated).
+// Folds the per-block partial sums in block order (double accumulation, fixed shuffle tree): coef[c] = (sum g / M,
+// sum g*xhat / M) and the BN parameter gradients (each BN parameter is produced exactly once per step, so they are
+// written, not accumulated).
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int two) {
     const int r = threadIdx.x & 15;
     const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -213,8 +224,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int t
     const double invM = 1.0 / (double)a.M;
     double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
     if (ok) {
-        s1 = a.red1[(size_t)r * 2 * a.C + 2 * c]; s2 = a.red1[(size_t)r * 2 * a.C + 2 * c + 1];
-        if (two) { t1 = a.red2[(size_t)r * 2 * a.C + 2 * c]; t2 = a.red2[(size_t)r * 2 * a.C + 2 * c + 1]; }
+        const float2* p1 = reinterpret_cast<const float2*>(a.part1) + c;
+        const float2* p2 = reinterpret_cast<const float2*>(a.part2) + c;
+#pragma unroll 4
+        for (int q = r; q < a.nparts; q += 16) {
+            const float2 v = p1[(size_t)q * a.C];
+            s1 += (double)v.x; s2 += (double)v.y;
+            if (two) { const float2 w = p2[(size_t)q * a.C]; t1 += (double)w.x; t2 += (double)w.y; }
+        }
     }
     s1 = fold16(s1); s2 = fold16(s2);
     if (two) { t1 = fold16(t1); t2 = fold16(t2); }
@@ -352,8 +369,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* pred, const float* target, long long n,
-                                                        double* loss_out, float* dl, int through_sigmoid) {
+                                                        double* loss_out, float* dl, int through_sigmoid, double* part,
+                                                        unsigned* counter) {
     __shared__ double wsum[4];
+    __shared__ int last_flag;
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float p = pred[i];
@@ -367,11 +386,22 @@ __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* pred, const
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(loss_out, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    // per-block partial, then the last arriving block adds the partials in block order (no atomics: the loss is
+    // bit-reproducible)
+    if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (!p3d_last_block(counter, gridDim.x, &last_flag)) return;
+    double t = 0.0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += part[b];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss_out += wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n4,
-                                                   long long n, float lr_t, float b1, float b2, float eps) {
+                                                   long long n, float lr_arg, const float* lr_dev, float b1, float b2, float eps) {
+    const float lr_t = lr_dev ? *lr_dev : lr_arg;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const long long e = i << 2;
         if (e + 3 < n) {
@@ -417,13 +447,21 @@ __global__ __launch_bounds__(256) void fill_uniform_kernel(float* p, long long n
         p[i] = lo + (hi - lo) * u01(seed, (unsigned long long)i);
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* dy, int ld, long long M, int C, float* out) {
-    // thread = one channel; blocks stride over rows; one atomic per (block, channel)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* dy, int ld, long long M, int C, float* out, float* part,
+                                                     unsigned* counters) {
+    // thread = one channel; blocks stride over rows; per-block partials, folded in block order by the last arriver of
+    // each channel group (no atomics)
+    __shared__ int last_flag;
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= C) return;
     float acc = 0.f;
-    for (long long row = blockIdx.x; row < M; row += gridDim.x) acc += dy[row * ld + c];
-    unsafeAtomicAdd(out + c, acc);
+    if (c < C)
+        for (long long row = blockIdx.x; row < M; row += gridDim.x) acc += dy[row * ld + c];
+    if (c < C) part[(size_t)blockIdx.x * C + c] = acc;
+    if (!p3d_last_block(counters + blockIdx.y, gridDim.x, &last_flag)) return;
+    if (c >= C) return;
+    float t = 0.f;
+    for (unsigned b = 0; b < gridDim.x; ++b) t += part[(size_t)b * C + c];
+    out[c] += t;
 }
 
 inline unsigned grid_for(long long total, int per_block = 256, int cap = 4096) {
@@ -436,18 +474,27 @@ inline unsigned grid_for(long long total, int per_block = 256, int cap = 4096) {
 }  // namespace
 
 hipError_t p3d_bn_finalize(const BnParams& bn, long M, int use_batch, int update_moving, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((bn.C + 15) / 16), dim3(256), 0, s, bn, 1.0 / (double)M, use_batch,
-                       update_moving, eps);
+    if (use_batch && (!bn.statpart || bn.nparts < 1)) return hipErrorInvalidValue;
+    if (use_batch && bn.nparts > 64)
+        hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3((bn.C + 3) / 4), dim3(256), 0, s, bn, 1.0 / (double)M, use_batch, update_moving, eps);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3((bn.C + 15) / 16), dim3(256), 0, s, bn, 1.0 / (double)M, use_batch, update_moving, eps);
     return hipGetLastError();
 }
 
-hipError_t p3d_bn_stats(const float* y, int ld, long M, int C, double* stats, hipStream_t s) {
-    if ((C & 3) || C > 1024 || (ld & 3)) return hipErrorInvalidValue;
+int p3d_bn_stats_parts(long M, int C) {
+    if ((C & 3) || C > 1024 || C < 4) return 0;
     const int rpi = 256 / (C >> 2);
     long long blocks = (M + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
     if (blocks < 1) blocks = 1;
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, ld, (long long)M, C, stats);
+    return (int)blocks;
+}
+
+hipError_t p3d_bn_stats(const float* y, int ld, long M, int C, float* statpart, hipStream_t s) {
+    if ((C & 3) || C > 1024 || (ld & 3)) return hipErrorInvalidValue;
+    const long long blocks = p3d_bn_stats_parts(M, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, ld, (long long)M, C, statpart);
     return hipGetLastError();
 }
 
@@ -465,13 +512,18 @@ hipError_t p3d_bn_apply(const BnApplyArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
-    if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
-    const int rpi = 256 / (a.C >> 2);
-    long long blocks = (a.M + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
+int p3d_bn_bwd_parts(long M, int C) {
+    if ((C & 3) || C > 1024 || C < 4) return 0;
+    const int rpi = 256 / (C >> 2);
+    long long blocks = (M + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
     if (blocks < 1) blocks = 1;
     if (blocks > 512) blocks = 512;
-    const unsigned g = (unsigned)blocks;
+    return (int)blocks;
+}
+
+hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
+    if ((a.C & 3) || a.C > 1024 || !a.part1 || a.nparts != p3d_bn_bwd_parts(a.M, a.C)) return hipErrorInvalidValue;
+    const unsigned g = (unsigned)a.nparts;
     switch (a.mode) {
         case 0: hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, dim3(g), dim3(256), 0, s, a); break;
         case 1: hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(g), dim3(256), 0, s, a); break;
@@ -600,15 +652,28 @@ hipError_t p3d_maxpool_bwd(const PoolArgs& a, hipStream_t s) {
 
 hipError_t p3d_smooth_l1(const float* pred, const float* target, long n, double* loss_out, float* dlogits,
                          int through_sigmoid, hipStream_t s) {
-    hipLaunchKernelGGL(smooth_l1_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, pred, target, (long long)n,
-                       loss_out, dlogits, through_sigmoid);
+    const unsigned g = grid_for(n, 256, 1024);
+    float* slab = nullptr; unsigned* cnt = nullptr;
+    const hipError_t e = p3d_stream_scratch(s, 2 * (size_t)g, 1, &slab, &cnt);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(g), dim3(256), 0, s, pred, target, (long long)n, loss_out, dlogits, through_sigmoid,
+                       reinterpret_cast<double*>(slab), cnt);
     return hipGetLastError();
 }
 
-hipError_t p3d_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
-                    hipStream_t s) {
+hipError_t p3d_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, const float* lr_dev, float b1, float b2,
+                    float eps, hipStream_t s) {
     const long long n4 = ((long long)n + 3) / 4;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4)), dim3(256), 0, s, p, g, m, v, n4, (long long)n, lr_t, b1, b2, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4)), dim3(256), 0, s, p, g, m, v, n4, (long long)n, lr_t, lr_dev, b1, b2, eps);
+    return hipGetLastError();
+}
+
+__global__ void set_step_scalars_kernel(unsigned long long* seed_dst, float* lr_dst, unsigned long long seed, float lr_t) {
+    if (seed_dst) *seed_dst = seed;
+    if (lr_dst) *lr_dst = lr_t;
+}
+hipError_t p3d_set_step_scalars(unsigned long long* seed_dst, float* lr_dst, unsigned long long seed, float lr_t, hipStream_t s) {
+    hipLaunchKernelGGL(set_step_scalars_kernel, dim3(1), dim3(1), 0, s, seed_dst, lr_dst, seed, lr_t);
     return hipGetLastError();
 }
 
@@ -635,7 +700,11 @@ hipError_t p3d_colsum(const float* dy, int ld, long M, int C, float* out, hipStr
     long long bx = (M + 63) / 64;
     if (bx > 512) bx = 512;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)bx, (C + 255) / 256), dim3(256), 0, s, dy, ld, (long long)M, C, out);
+    const unsigned gy = (unsigned)((C + 255) / 256);
+    float* slab = nullptr; unsigned* cnt = nullptr;
+    const hipError_t e = p3d_stream_scratch(s, (size_t)bx * C, gy, &slab, &cnt);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)bx, gy), dim3(256), 0, s, dy, ld, (long long)M, C, out, slab, cnt);
     return hipGetLastError();
 }
 

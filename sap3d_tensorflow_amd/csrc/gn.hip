@@ -9,6 +9,8 @@
 // 4 r + relu(gn(y1)) (ST_C); 5 gn(y1); 6 relu(gn(y1) + r * cs[n,c] * ss[pos]) (CBAM-scaled residual,
 // gn/p3d_gn.py:175-177 with utils/network.py:249,274 folded in).
 #include "p3d_kernels.h"
+#include "det_reduce.h"
+#define P3D_SEED(a) ((a).seed_dev ? *(a).seed_dev : (a).seed)   // wave-uniform; device-resident under graph replay
 
 namespace {
 
@@ -38,8 +40,10 @@ __device__ __forceinline__ float4 dropmask4(unsigned long long seed, long long e
 }
 
 // ---- statistics: sums[n][c] += (sum, sumsq) over a slice of the sample's rows.  grid = (row slices, N).
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* y, int ld, int R, int C, double* sums) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* y, int ld, int R, int C, double* sums, float* part,
+                                                       unsigned* counters) {
     __shared__ float red[256][8];
+    __shared__ int last_flag;
     const int c4n = C >> 2, rpi = 256 / c4n;
     const int tid = threadIdx.x, sub = tid / c4n, c = (tid - sub * c4n) << 2;
     const int n = blockIdx.y;
@@ -60,12 +64,24 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* y, int ld, i
         for (int s = 0; s < rpi; ++s)
 #pragma unroll
             for (int k = 0; k < 8; ++k) t[k] += red[s * c4n + tid][k];
-        double* dst = sums + ((long long)n * C + c) * 2;
+        // this row slice's partial (plain stores); the last arriving slice of the sample folds them in slice order
+        float* dst = part + (((size_t)blockIdx.x * gridDim.y + n) * C + c) * 2;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            unsafeAtomicAdd(dst + 2 * k, (double)t[k]);
-            unsafeAtomicAdd(dst + 2 * k + 1, (double)t[4 + k]);
+        for (int k = 0; k < 4; ++k) { dst[2 * k] = t[k]; dst[2 * k + 1] = t[4 + k]; }
+    }
+    if (!p3d_last_block(counters + n, gridDim.x, &last_flag)) return;
+    if (tid < c4n) {
+        double acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) {
+            const float* src = part + (((size_t)b * gridDim.y + n) * C + c) * 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += (double)src[k];
         }
+        double* out = sums + ((long long)n * C + c) * 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = acc[k];
     }
 }
 
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
         else if (MODE == 3) z = add4(relu4(v), relu4(fma4(ld4(a.g2.scale + t), ld4(a.y2 + row * a.ld2 + c), ld4(a.g2.shift + t))));
         else if (MODE == 4) z = add4(ld4(a.y2 + row * a.ld2 + c), relu4(v));
         else z = relu4(add4(v, mul4(mul4(ld4(a.y2 + row * a.ld2 + c), ld4(a.cs + t)), f4(a.ss[row]))));
-        if (a.drop_scale > 0.f) z = mul4(z, dropmask4(a.seed, row * a.C + c, a.drop_rate, a.drop_scale));
+        if (a.drop_scale > 0.f) z = mul4(z, dropmask4(P3D_SEED(a), row * a.C + c, a.drop_rate, a.drop_scale));
         st4(a.z + row * a.ldz + c, z);
     }
 }
@@ -118,7 +134,7 @@ template <int MODE>
 __device__ __forceinline__ void gn_gates(const GnApplyArgs& a, long long row, int c, long long t, float4& g1, float4& g2,
                                          float4& y1, float4& y2) {
     float4 dz = ld4(a.dz + row * a.ldz + c);
-    if (a.drop_scale > 0.f) dz = mul4(dz, dropmask4(a.seed, row * a.C + c, a.drop_rate, a.drop_scale));
+    if (a.drop_scale > 0.f) dz = mul4(dz, dropmask4(P3D_SEED(a), row * a.C + c, a.drop_rate, a.drop_scale));
     y1 = ld4(a.y1 + row * a.ld1 + c);
     const float4 v1 = fma4(ld4(a.g1.scale + t), y1, ld4(a.g1.shift + t));
     y2 = f4(0.f); g2 = f4(0.f);
@@ -142,6 +158,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnApplyArgs a) {
     constexpr bool TWO = (MODE == 3);
     __shared__ float red[256][TWO ? 16 : 8];
+    __shared__ int last_flag;
     const int c4n = a.C >> 2, rpi = 256 / c4n;
     const int tid = threadIdx.x, sub = tid / c4n, c = (tid - sub * c4n) << 2;
     const int n = blockIdx.y;
@@ -172,14 +189,30 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnApplyArgs a) {
         for (int s = 0; s < rpi; ++s)
 #pragma unroll
             for (int k = 0; k < NV; ++k) tt[k] += red[s * c4n + tid][k];
+        // this row slice's partials (plain stores, [slice][n][C][NV/4 pairs]); folded in slice order by the last arriver
+        float* dst = a.part + (((size_t)blockIdx.x * gridDim.y + n) * a.C + c) * (NV / 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            unsafeAtomicAdd(a.g1.sums + (t + k) * 2, (double)tt[k]);
-            unsafeAtomicAdd(a.g1.sums + (t + k) * 2 + 1, (double)tt[4 + k]);
-            if (TWO) {
-                unsafeAtomicAdd(a.g2.sums + (t + k) * 2, (double)tt[8 + k]);
-                unsafeAtomicAdd(a.g2.sums + (t + k) * 2 + 1, (double)tt[12 + k]);
-            }
+            dst[k * (NV / 4) + 0] = tt[k]; dst[k * (NV / 4) + 1] = tt[4 + k];
+            if (TWO) { dst[k * (NV / 4) + 2] = tt[8 + k]; dst[k * (NV / 4) + 3] = tt[12 + k]; }
+        }
+    }
+    if (!p3d_last_block(a.counters + n, gridDim.x, &last_flag)) return;
+    if (tid < c4n) {
+        constexpr int NV = TWO ? 16 : 8;
+        double acc[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) {
+            const float* src = a.part + (((size_t)b * gridDim.y + n) * a.C + c) * (NV / 4);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[k] += (double)src[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a.g1.sums[(t + k) * 2] = acc[k * (NV / 4) + 0];
+            a.g1.sums[(t + k) * 2 + 1] = acc[k * (NV / 4) + 1];
+            if (TWO) { a.g2.sums[(t + k) * 2] = acc[k * (NV / 4) + 2]; a.g2.sums[(t + k) * 2 + 1] = acc[k * (NV / 4) + 3]; }
         }
     }
 }
@@ -317,7 +350,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd_kernel(GnApplyArgs a) {
             else if (MODE == 3) z = add4(relu4(v), relu4(fma4(sc2, v2[j], sh2)));
             else if (MODE == 4) z = add4(v2[j], relu4(v));
             else z = relu4(add4(v, mul4(mul4(v2[j], cs), f4(a.ss[row]))));
-            if (a.drop_scale > 0.f) z = mul4(z, dropmask4(a.seed, row * a.C + c, a.drop_rate, a.drop_scale));
+            if (a.drop_scale > 0.f) z = mul4(z, dropmask4(P3D_SEED(a), row * a.C + c, a.drop_rate, a.drop_scale));
             st4(a.z + row * a.ldz + c, z);
         }
     }
@@ -363,14 +396,11 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GnApplyArgs a) {
             for (int k = 0; k < (TWO ? 4 : 2); ++k) tt[k] = add4(tt[k], red[q * c4n + threadIdx.x][k]);
 #pragma unroll
         for (int k = 0; k < (TWO ? 4 : 2); ++k) red[threadIdx.x][k] = tt[k];      // (row lane 0 slot: safe, only this thread reads it)
-        const float b1[4] = {tt[0].x, tt[0].y, tt[0].z, tt[0].w}, x1[4] = {tt[1].x, tt[1].y, tt[1].z, tt[1].w};
+        // per-sample partial parameter gradients [n][C][4 float4 slots]; summed over samples, in sample order, by the
+        // block of this group that finishes last (end of the kernel)
+        float4* pp = reinterpret_cast<float4*>(a.part) + ((size_t)n * a.C + c);      // slot k at pp[k]: row stride is 4 channels
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(a.dbeta1 + c + k, b1[k]); unsafeAtomicAdd(a.dgamma1 + c + k, x1[k]); }
-        if (TWO) {
-            const float b2[4] = {tt[2].x, tt[2].y, tt[2].z, tt[2].w}, x2[4] = {tt[3].x, tt[3].y, tt[3].z, tt[3].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(a.dbeta2 + c + k, b2[k]); unsafeAtomicAdd(a.dgamma2 + c + k, x2[k]); }
-        }
+        for (int k = 0; k < (TWO ? 4 : 2); ++k) pp[k] = tt[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {                         // gamma-weighted group sums -> the two mean terms
@@ -403,6 +433,25 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GnApplyArgs a) {
             }
         }
     }
+    // parameter gradients: the block of this group that finishes last adds the per-sample partials in sample order
+    __shared__ int last_flag;
+    if (!p3d_last_block(a.counters + blockIdx.x, gridDim.y, &last_flag)) return;
+    if (threadIdx.x < c4n) {
+        float4 acc[TWO ? 4 : 2];
+#pragma unroll
+        for (int k = 0; k < (TWO ? 4 : 2); ++k) acc[k] = f4(0.f);
+        for (unsigned n2 = 0; n2 < gridDim.y; ++n2) {
+            const float4* pp = reinterpret_cast<const float4*>(a.part) + ((size_t)n2 * a.C + c);
+#pragma unroll
+            for (int k = 0; k < (TWO ? 4 : 2); ++k) acc[k] = add4(acc[k], pp[k]);
+        }
+        st4(a.dbeta1 + c, add4(ld4(a.dbeta1 + c), acc[0]));
+        st4(a.dgamma1 + c, add4(ld4(a.dgamma1 + c), acc[1]));
+        if (TWO) {
+            st4(a.dbeta2 + c, add4(ld4(a.dbeta2 + c), acc[2]));
+            st4(a.dgamma2 + c, add4(ld4(a.dgamma2 + c), acc[3]));
+        }
+    }
 }
 
 inline unsigned grid_for(long long total, int cap = 4096) {
@@ -423,7 +472,11 @@ inline dim3 slice_grid(int R, int C, int N) {
 
 hipError_t p3d_gn_stats(const float* y, int ld, int N, int R, int C, double* sums, hipStream_t s) {
     if ((C & 3) || C > 1024 || (ld & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_stats_kernel, slice_grid(R, C, N), dim3(256), 0, s, y, ld, R, C, sums);
+    const dim3 grid = slice_grid(R, C, N);
+    float* part = nullptr; unsigned* cnt = nullptr;
+    const hipError_t e = p3d_stream_scratch(s, (size_t)grid.x * N * C * 2, (size_t)N, &part, &cnt);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, y, ld, R, C, sums, part, cnt);
     return hipGetLastError();
 }
 hipError_t p3d_gn_finalize(const GnParams& p, int N, int R, float eps, hipStream_t s) {
@@ -451,9 +504,13 @@ hipError_t p3d_gn_apply(const GnApplyArgs& a, hipStream_t s) {
     P3D_GN_SWITCH(gn_apply_kernel, g)
     return hipGetLastError();
 }
-hipError_t p3d_gn_bwd_reduce(const GnApplyArgs& a, hipStream_t s) {
-    if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
-    const dim3 g = slice_grid(a.R, a.C, (int)(a.M / a.R));
+hipError_t p3d_gn_bwd_reduce(const GnApplyArgs& a0, hipStream_t s) {
+    if ((a0.C & 3) || a0.C > 1024) return hipErrorInvalidValue;
+    const int N = (int)(a0.M / a0.R);
+    const dim3 g = slice_grid(a0.R, a0.C, N);
+    GnApplyArgs a = a0;
+    const hipError_t e = p3d_stream_scratch(s, (size_t)g.x * N * a.C * 4, (size_t)N, &a.part, &a.counters);
+    if (e != hipSuccess) return e;
     P3D_GN_SWITCH(gn_bwd_reduce_kernel, g)
     return hipGetLastError();
 }
@@ -481,9 +538,12 @@ hipError_t p3d_gn_small_fwd(const GnApplyArgs& a, hipStream_t s) {
     P3D_GN_SWITCH(gn_small_fwd_kernel, g)
     return hipGetLastError();
 }
-hipError_t p3d_gn_small_bwd(const GnApplyArgs& a, hipStream_t s) {
-    if (!p3d_gn_small_ok(a.R, a.C, a.g1.G) || (a.M % a.R)) return hipErrorInvalidValue;
-    const dim3 g((unsigned)a.g1.G, (unsigned)(a.M / a.R));
+hipError_t p3d_gn_small_bwd(const GnApplyArgs& a0, hipStream_t s) {
+    if (!p3d_gn_small_ok(a0.R, a0.C, a0.g1.G) || (a0.M % a0.R)) return hipErrorInvalidValue;
+    const dim3 g((unsigned)a0.g1.G, (unsigned)(a0.M / a0.R));
+    GnApplyArgs a = a0;
+    const hipError_t e = p3d_stream_scratch(s, (size_t)g.y * a.C * 4, (size_t)g.x, &a.part, &a.counters);
+    if (e != hipSuccess) return e;
     P3D_GN_SWITCH(gn_small_bwd_kernel, g)
     return hipGetLastError();
 }

@@ -9,6 +9,7 @@
 // dgrad   : dx[g,c] = sum_k dlogits[2g+k] * K[k,0,c]   (27 taps, bounds-checked)
 // wgrad   : dK[k,0,c] = sum_g dlogits[2g+k] * x[g,c],  dbias = sum dlogits
 #include "p3d_kernels.h"
+#include "det_reduce.h"
 
 namespace {
 
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void head_bwd_filter_kernel(HeadArgs a) {
         if (threadIdx.x < C) {
             float s = 0.f;
             for (int l = 0; l < lanes; ++l) s += red[l * C + threadIdx.x];
-            unsafeAtomicAdd(a.dk + q * C + threadIdx.x, s);
+            a.part[((size_t)blockIdx.x * 28 + q) * C + threadIdx.x] = s;
         }
         __syncthreads();
     }
@@ -151,7 +152,17 @@ __global__ __launch_bounds__(256) void head_bwd_filter_kernel(HeadArgs a) {
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int l = 0; l < lanes; ++l) s += red[l * C];
-        unsafeAtomicAdd(a.dbias, s);
+        a.part[((size_t)blockIdx.x * 28 + 27) * C] = s;
+    }
+    // the last arriving block adds every block's partial filter gradient in block order (no atomics)
+    __shared__ int last_flag;
+    if (!p3d_last_block(a.counter, gridDim.x, &last_flag)) return;
+    for (int i = threadIdx.x; i < 27 * C + 1; i += blockDim.x) {
+        const size_t slot = i < 27 * C ? (size_t)i : (size_t)27 * C;
+        float t = 0.f;
+#pragma unroll 8
+        for (unsigned b = 0; b < gridDim.x; ++b) t += a.part[(size_t)b * 28 * C + slot];
+        if (i < 27 * C) a.dk[i] += t; else a.dbias[0] += t;
     }
 }
 
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(256) void headc_bwd_filter_kernel(HeadArgs a) {
         if (threadIdx.x < C) {
             float s = 0.f;
             for (int l = 0; l < lanes; ++l) s += red[l * C + threadIdx.x];
-            unsafeAtomicAdd(a.dk + q * C + threadIdx.x, s);
+            a.part[((size_t)blockIdx.x * 28 + q) * C + threadIdx.x] = s;
         }
         __syncthreads();
     }
@@ -275,7 +286,17 @@ __global__ __launch_bounds__(256) void headc_bwd_filter_kernel(HeadArgs a) {
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int l = 0; l < lanes; ++l) s += red[l * C];
-        unsafeAtomicAdd(a.dbias, s);
+        a.part[((size_t)blockIdx.x * 28 + 27) * C] = s;
+    }
+    // the last arriving block adds every block's partial filter gradient in block order (no atomics)
+    __shared__ int last_flag;
+    if (!p3d_last_block(a.counter, gridDim.x, &last_flag)) return;
+    for (int i = threadIdx.x; i < 27 * C + 1; i += blockDim.x) {
+        const size_t slot = i < 27 * C ? (size_t)i : (size_t)27 * C;
+        float t = 0.f;
+#pragma unroll 8
+        for (unsigned b = 0; b < gridDim.x; ++b) t += a.part[(size_t)b * 28 * C + slot];
+        if (i < 27 * C) a.dk[i] += t; else a.dbias[0] += t;
     }
 }
 
@@ -304,9 +325,12 @@ hipError_t p3d_headc_bwd_filter(const HeadArgs& a, hipStream_t s) {
     const long long total = (long long)a.N * a.D * a.H * a.W;
     const int lanes = 256 / a.C;
     long long b = (total + (long long)lanes * 32 - 1) / ((long long)lanes * 32);
-    if (b > 1024) b = 1024;
+    if (b > 256) b = 256;       // the last arriving block folds b partial gradients: keep that tail short
     if (b < 1) b = 1;
-    hipLaunchKernelGGL(headc_bwd_filter_kernel, dim3((unsigned)b), dim3(256), 0, s, a);
+    HeadArgs aa = a;
+    const hipError_t e = p3d_stream_scratch(s, (size_t)b * 28 * a.C, 1, &aa.part, &aa.counter);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(headc_bwd_filter_kernel, dim3((unsigned)b), dim3(256), 0, s, aa);
     return hipGetLastError();
 }
 
@@ -333,8 +357,11 @@ hipError_t p3d_head_bwd_filter(const HeadArgs& a, hipStream_t s) {
     const long long total = (long long)a.N * a.D * a.H * a.W;
     const int lanes = 256 / a.C;
     long long b = (total + (long long)lanes * 32 - 1) / ((long long)lanes * 32);
-    if (b > 1024) b = 1024;
+    if (b > 256) b = 256;       // the last arriving block folds b partial gradients: keep that tail short
     if (b < 1) b = 1;
-    hipLaunchKernelGGL(head_bwd_filter_kernel, dim3((unsigned)b), dim3(256), 0, s, a);
+    HeadArgs aa = a;
+    const hipError_t e = p3d_stream_scratch(s, (size_t)b * 28 * a.C, 1, &aa.part, &aa.counter);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(head_bwd_filter_kernel, dim3((unsigned)b), dim3(256), 0, s, aa);
     return hipGetLastError();
 }

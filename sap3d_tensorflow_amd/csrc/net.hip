@@ -73,7 +73,9 @@ struct BN {
     std::string name;
     int C = 0;
     Param *gamma = nullptr, *beta = nullptr, *mm = nullptr, *mv = nullptr;
-    int64_t stats_off = 0;          // into the stats arena (doubles)
+    int64_t part_off = -1;          // statistics partials [part_cap][C][2] floats in statpart_arena (-1: producer has no epilogue)
+    int part_cap = 0;
+    int nparts = 0;                 // partials the last forward's producer wrote (host-side, set at enqueue)
     float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;
     bool follows_flag = false;      // obeys the `training` placeholder (stem / decoder); else always batch stats
     bool used_batch = true;         // what the last forward used
@@ -114,6 +116,8 @@ struct Ctx {
     bool training = false;
     float drop = 0.f;
     uint64_t seed = 0;
+    const unsigned long long* seed_dev = nullptr;   // captured step graphs: dropout seed and Adam step size live in device memory
+    const float* lr_dev = nullptr;
     bool update_moving = false;
     bool per_sample = false;          // batch-statistics BNs normalise every clip by its own statistics (p3d_predict_windows)
     hipStream_t s = nullptr;
@@ -169,34 +173,32 @@ void launch_igemm(const Ctx& c, const IgemmArgs& a0, int allow_split = 0) {
 
 void zero_strided(const Ctx& c, float* p, int ld, int64_t rows, int C);
 
+// Where a producer's BatchNorm-statistics epilogue puts its per-tile partial sums, and how many it wrote
+// (read by p3d_bn_finalize right after, on the same stream).
+struct StatSink { float* part = nullptr; int cap = 0; int* nparts = nullptr; };
+
 // A group of implicit-GEMM launches that together produce one output tensor (one conv forward,
-// or the residue classes of an input gradient / transposed conv).  Lets small problems slice K
-// across blocks: the output is zeroed first (unless it already holds a value to accumulate into)
-// and every launch then adds into it; statistics move to a separate pass.
+// or the residue classes of an input gradient / transposed conv).  Small problems slice K across blocks;
+// the slices are folded in a fixed order by the last arriving block (conv_igemm2.hip), so the output needs no
+// zero fill and the statistics epilogue and accumulate mode work either way.
 void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld, int64_t rows, int C, bool accumulate,
-                     double* stats) {
-    bool any_split = false;
+                     const StatSink* stats) {
+    (void)out; (void)ld; (void)rows; (void)C;
+    int base = 0;
     for (auto& a : v) {
-        if (a.stem_wfloats) continue;
-        IgemmArgs t = a;
-        t.stats = nullptr; t.accum = 0;
-        if (p3d_igemm2_plan(t, 1).splits > 1) any_split = true;
+        a.accum = accumulate ? 1 : 0;
+        a.statpart = nullptr; a.stat_base = 0;
+        if (stats && stats->part && !a.stem_wfloats) {
+            IgemmArgs t = a; t.zeros = g_zero_page;
+            const P3dIgemmPlan pl = p3d_igemm2_plan(t, 1);
+            const int mt = p3d_igemm2_mtiles(t, pl);
+            if (base + mt > stats->cap) throw P3dError("statistics partials overflow their arena slot");
+            a.statpart = stats->part; a.stat_base = base;
+            base += mt;
+        }
+        launch_igemm(c, a, 1);
     }
-    if (!any_split) {
-        for (auto& a : v) { a.accum = accumulate ? 1 : 0; a.stats = stats; launch_igemm(c, a, 0); }
-        return;
-    }
-    if (!accumulate) zero_strided(c, out, ld, rows, C);
-    for (auto& a : v) {
-        a.stats = nullptr;
-        IgemmArgs t = a;
-        t.accum = 0;
-        const bool split = p3d_igemm2_plan(t, 1).splits > 1;
-        a.accum = split ? 0 : 1;          // split launches add atomically; whole-K launches add with a plain RMW
-        launch_igemm(c, a, split ? 1 : 0);
-    }
-    if (stats)
-        launch(c, "bn_stats_kernel", 0, 4.0 * rows * C, [&]() { return p3d_bn_stats(out, ld, rows, C, stats, c.s); });
+    if (stats && stats->nparts) *stats->nparts = base;
 }
 
 // Runs `f(side_ctx)` on the side stream after everything queued so far on the main stream.
@@ -264,7 +266,7 @@ void stemify(const ConvGeo& g, int Cin, int& K, int& ntaps, P3dTap* taps, int& w
 
 // ---- launch-argument builders on the shared geometry ---------------------------------------------
 IgemmArgs igemm_conv_forward(const ConvGeo& g, int N, const float* x, int ldx, int Cin, float* y, int ldy, int Cout,
-                             const float* w, const float* bias, double* stats, int accum, bool stem = false) {
+                             const float* w, const float* bias, int accum, bool stem = false) {
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.N = N; a.Di = g.I[0]; a.Hi = g.I[1]; a.Wi = g.I[2]; a.ldx = ldx; a.K = Cin;
@@ -272,7 +274,7 @@ IgemmArgs igemm_conv_forward(const ConvGeo& g, int N, const float* x, int ldx, i
     a.isd = g.s[0]; a.ish = g.s[1]; a.isw = g.s[2];
     a.y = y; a.Do = g.O[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.ldy = ldy; a.Nc = Cout;
     a.osd = a.osh = a.osw = 1;
-    a.w = w; a.wT = 0; a.bias = bias; a.stats = stats; a.accum = accum;
+    a.w = w; a.wT = 0; a.bias = bias; a.accum = accum;
     if (stem) {
         stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
         return a;
@@ -296,7 +298,7 @@ IgemmArgs igemm_conv_forward(const ConvGeo& g, int N, const float* x, int ldx, i
 // conv-input lattice.  `dense` has the conv's OUTPUT extents, `out` the conv's INPUT extents.
 std::vector<IgemmArgs> igemm_conv_input_side(const ConvGeo& g, int N, const float* dense, int ld_dense, int Cdense,
                                              float* out, int ld_out, int Cout_side, const float* w,
-                                             const float* bias, double* stats, int accum, bool include_empty) {
+                                             const float* bias, int accum, bool include_empty) {
     std::vector<IgemmArgs> v;
     for (int pd = 0; pd < g.s[0]; ++pd)
         for (int ph = 0; ph < g.s[1]; ++ph)
@@ -317,7 +319,7 @@ std::vector<IgemmArgs> igemm_conv_input_side(const ConvGeo& g, int N, const floa
                 a.y = out; a.Do = g.I[0]; a.Ho = g.I[1]; a.Wo = g.I[2]; a.ldy = ld_out; a.Nc = Cout_side;
                 a.osd = g.s[0]; a.osh = g.s[1]; a.osw = g.s[2];
                 a.ood = pd; a.ooh = ph; a.oow = pw;
-                a.w = w; a.wT = 1; a.bias = bias; a.stats = stats; a.accum = accum;
+                a.w = w; a.wT = 1; a.bias = bias; a.accum = accum;
                 int t = 0;
                 for (int kd = 0; kd < g.k[0]; ++kd) {
                     if (pmod(pd + g.pad[0] - kd, g.s[0])) continue;
@@ -563,23 +565,83 @@ struct p3d_handle {
         bn->beta = add_param(bn->name + "/beta", {C}, true, INIT_ZEROS);
         bn->mm = add_param(bn->name + "/moving_mean", {C}, false, INIT_ZEROS);
         bn->mv = add_param(bn->name + "/moving_variance", {C}, false, INIT_ONES);
-        bn->stats_off = stats_count; stats_count += (int64_t)P3D_STAT_REPLICAS * 2 * C;
         const int64_t o = bnbuf_count; bnbuf_count += 4 * (int64_t)C;
         late_bind.push_back([this, bn, o, C]() {
             bn->scale = bnbuf + o; bn->shift = bnbuf + o + C; bn->mean = bnbuf + o + 2 * C; bn->invstd = bnbuf + o + 3 * C;
         });
         return bn;
     }
-    double* bn_stats(BN* bn) { return stats_arena + bn->stats_off; }
+    // Reserve room for the producer's per-tile statistics partials of a `rows`-row output: one per 64-row tile of
+    // every launch of the group (residue classes of a transposed conv: up to 64), or per block of p3d_bn_stats.
+    float* statpart_arena = nullptr; int64_t statpart_count = 0;
+    void reserve_stat_parts(BN* bn, int64_t rows) {
+        if (bn->part_off >= 0) return;
+        bn->part_cap = (int)std::max<int64_t>(rows / 64 + 80, p3d_bn_stats_parts((long)rows, bn->C));
+        bn->part_off = statpart_count;
+        statpart_count += (int64_t)bn->part_cap * bn->C * 2;
+    }
+    StatSink bn_sink(BN* bn) {
+        if (bn->part_off < 0) throw P3dError("BatchNorm " + bn->name + " has no statistics arena slot");
+        StatSink s; s.part = statpart_arena + bn->part_off; s.cap = bn->part_cap; s.nparts = &bn->nparts;
+        return s;
+    }
     // Producers of tensors that the one-launch small-tensor BN will consume need no statistics epilogue.
     static bool bn_is_small(int64_t rows, int C, bool dropout = false) { return !dropout && p3d_bn_small_ok((long)rows, C); }
     BN* stats_target(BN* bn, int64_t rows, int C, bool dropout = false) { return bn_is_small(rows, C, dropout) ? nullptr : bn; }
     BnParams bn_params(BN* bn) {
         BnParams b;
         b.gamma = bn->gamma->p; b.beta = bn->beta->p; b.moving_mean = bn->mm->p; b.moving_var = bn->mv->p;
-        b.stats = bn_stats(bn); b.scale = bn->scale; b.shift = bn->shift; b.mean = bn->mean; b.invstd = bn->invstd;
+        b.statpart = bn->part_off >= 0 ? statpart_arena + bn->part_off : nullptr; b.nparts = bn->nparts; b.scale = bn->scale; b.shift = bn->shift; b.mean = bn->mean; b.invstd = bn->invstd;
         b.C = bn->C;
         return b;
+    }
+
+    // ---- deferred, grouped weight gradients -------------------------------------------------------
+    // A conv's filter gradient needs only its input and its output gradient, both of which stay untouched until the
+    // step ends, and nothing waits for it before the all-reduce / optimiser.  So backward does not launch it on the
+    // spot: problems queue up and go to the side stream several at a time (p3d_launch_wgrad2_group) -- the four
+    // filter gradients of a stage-3 bottleneck offer 320 output tiles together, enough for the 256 CUs without
+    // cutting the 784-position reduction.  Flushed when a group is full, before a gradient bucket is handed to the
+    // all-reduce, and at the end of backward.
+    struct PendingWgrad { WgradArgs a; std::string op; double flops, bytes; };
+    std::vector<PendingWgrad> wq;
+    std::vector<hipEvent_t> wq_events;          // one fork event per flush of a backward pass, reused every step
+    size_t wq_flushes = 0;
+    static int64_t wgrad_tiles64(const WgradArgs& a) { return (int64_t)a.ntaps * ((a.K + 63) / 64) * ((a.Nc + 63) / 64); }
+    void queue_wgrad(const Ctx& c, const WgradArgs& a0) {
+        if (c.dry) return;
+        WgradArgs a = a0;
+        a.zeros = g_zero_page;
+        const double M = (double)a.N * a.Gd * a.Gh * a.Gw;
+        const double side = (double)a.N * a.Di * a.Hi * a.Wi;
+        PendingWgrad pw;
+        pw.a = a; pw.op = c.prof ? c.prof->cur_op : std::string();
+        pw.flops = 2.0 * M * a.ntaps * (double)a.K * a.Nc;
+        pw.bytes = 4.0 * (std::min(M * a.ntaps, side) * a.K + M * a.Nc + (double)a.ntaps * a.K * a.Nc);
+        static const bool no_group = getenv("P3D_NO_WGRAD_GROUP") != nullptr;
+        const bool alone = no_group || wgrad_tiles64(a) >= 256;      // fills the chip by itself (and may take 128x128 tiles)
+        if (alone) flush_wgrads(c);
+        wq.push_back(pw);
+        int64_t tiles = 0;
+        for (auto& q : wq) tiles += wgrad_tiles64(q.a);
+        if (alone || (int)wq.size() == P3D_WGRAD_GROUP || tiles >= 256) flush_wgrads(c);
+    }
+    void flush_wgrads(const Ctx& c) {
+        if (wq.empty() || c.dry) { wq.clear(); return; }
+        if (wq_flushes >= wq_events.size()) {
+            hipEvent_t e = nullptr;
+            HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            wq_events.push_back(e);
+        }
+        hipEvent_t ev = wq_events[wq_flushes++];
+        std::vector<WgradArgs> probs;
+        double fl = 0, by = 0;
+        for (auto& q : wq) { probs.push_back(q.a); fl += q.flops; by += q.bytes; }
+        const char* name = probs.size() == 1 ? p3d_wgrad2_variant(probs[0]) : "wgrad2_kernel<64,64>(grouped)";
+        on_side_stream(c, ev, [&](const Ctx& sc) {
+            launch(sc, name, fl, by, [&]() { return p3d_launch_wgrad2_group(probs.data(), (int)probs.size(), sc.s); });
+        });
+        wq.clear();
     }
 
     // ---- graph ops ---------------------------------------------------------------------------
@@ -588,6 +650,7 @@ struct p3d_handle {
               const std::string& out_name, bool stem = false, bool bn_has_dropout = false, bool fwd_on_side = false) {
         const ConvGeo g = make_geo(x->D, x->H, x->W, k, s);
         Act* y = new_act(out_name, x->N, g.O[0], g.O[1], g.O[2], Cout);
+        if (bn && stats_target(bn, y->rows(), Cout, bn_has_dropout)) reserve_stat_parts(bn, y->rows());
         char* xflag = x->g ? consume(x) : nullptr;
         const int Cin = x->C;
         const int ntap = k[0] * k[1] * k[2];
@@ -626,12 +689,8 @@ struct p3d_handle {
                 a.osd = a.osh = a.osw = 1; a.w = w4;
                 std::vector<IgemmArgs> v{a};
                 BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
-                static const bool sep = getenv("P3D_STEM_SEPSTATS") != nullptr;
-                if (sep && sbn) {
-                    run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, nullptr);
-                    launch(c, "bn_stats_kernel", 0, 4.0 * y->rows() * Cout, [&]() { return p3d_bn_stats(y->p, y->ld, y->rows(), Cout, bn_stats(sbn), c.s); });
-                } else
-                run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? bn_stats(sbn) : nullptr);
+                StatSink sink; if (sbn) sink = bn_sink(sbn);
+                run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? &sink : nullptr);
             };
             op.bwd = [=](const Ctx& c) {
                 on_side_stream(c, fork_ev, [&](const Ctx& sc) {
@@ -656,10 +715,11 @@ struct p3d_handle {
         }
         auto fwd_body = [=](const Ctx& c) {
             std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
-                                                        nullptr, 0, stem)};
+                                                        0, stem)};
             if (ntap == 1 && !stem && pointwise_f16) v[0].f16 = 1;
             BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
-            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? bn_stats(sbn) : nullptr);
+            StatSink sink; if (sbn) sink = bn_sink(sbn);
+            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? &sink : nullptr);
         };
         // fwd_on_side: this conv has a sibling that reads the same input (ST_B, p3d.py:65-72); it runs on the side
         // stream next to it and the caller joins the streams (join_side) before their outputs are combined
@@ -669,13 +729,10 @@ struct p3d_handle {
             else fwd_body(c);
         };
         op.bwd = [=](const Ctx& c) {
-            on_side_stream(c, fork_ev, [&](const Ctx& sc) {
-                WgradArgs wa = wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr, stem);
-                launch_wgrad(sc, wa);
-            });
+            queue_wgrad(c, wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr, stem));
             if (xflag) {
                 const int accum = *xflag;
-                auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, w->p, nullptr, nullptr, accum,
+                auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, w->p, nullptr, accum,
                                                /*include_empty=*/!accum);
                 if (ntap == 1 && !stem && pointwise_f16) for (auto& a : v) a.f16 = 1;
                 run_igemm_group(c, v, x->g, x->ld, x->rows(), Cin, accum != 0, nullptr);
@@ -704,6 +761,7 @@ struct p3d_handle {
                 const std::string& out_name, bool bn_has_dropout = false) {
         const ConvGeo g = make_geo(x->D * s[0], x->H * s[1], x->W * s[2], k, s);    // conv whose input is y
         Act* y = new_act(out_name, x->N, g.I[0], g.I[1], g.I[2], Cout);
+        if (bn && stats_target(bn, y->rows(), Cout, bn_has_dropout)) reserve_stat_parts(bn, y->rows());
         char* xflag = x->g ? consume(x) : nullptr;
         const int Cin = x->C;
         Op op;
@@ -717,20 +775,20 @@ struct p3d_handle {
         hipEvent_t fork_ev = new_fork_event();
         op.fwd = [=](const Ctx& c) {
             auto v = igemm_conv_input_side(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, kern->p, bias ? bias->p : nullptr,
-                                           nullptr, 0, true);
+                                           0, true);
             BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
-            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? bn_stats(sbn) : nullptr);
+            StatSink sink; if (sbn) sink = bn_sink(sbn);
+            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? &sink : nullptr);
         };
         op.bwd = [=](const Ctx& c) {
             // dK[tap][co][ci] = sum dy_big[o][co] * x[i][ci]  (conv wgrad with the roles of x and dy swapped)
-            on_side_stream(c, fork_ev, [&](const Ctx& sc) {
-                WgradArgs wa = wgrad_conv(g, x->N, y->g, y->ld, Cout, x->p, x->ld, Cin, kern->g, nullptr);
-                launch_wgrad(sc, wa);
-                if (bias)
+            queue_wgrad(c, wgrad_conv(g, x->N, y->g, y->ld, Cout, x->p, x->ld, Cin, kern->g, nullptr));
+            if (bias)
+                on_side_stream(c, fork_ev, [&](const Ctx& sc) {
                     launch(sc, "colsum_kernel", 0, 4.0 * y->rows() * Cout, [&]() { return p3d_colsum(y->g, y->ld, y->rows(), Cout, bias->g, sc.s); });
-            });
+                });
             if (xflag) {
-                std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, kern->p, nullptr, nullptr, *xflag)};
+                std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, kern->p, nullptr, *xflag)};
                 run_igemm_group(c, v, x->g, x->ld, x->rows(), Cin, *xflag != 0, nullptr);
             }
         };
@@ -747,8 +805,9 @@ struct p3d_handle {
         char* f2 = nullptr;
         if (y2) f2 = consume(y2);
         const bool two = (mode == 2 || mode == 3);
-        const int64_t red_off = red_count;
-        red_count += (two ? 2 : 1) * (int64_t)P3D_STAT_REPLICAS * 2 * y1->C;
+        const int bwd_parts = p3d_bn_bwd_parts((long)y1->rows(), y1->C);
+        const int64_t red_off = statpart_count;          // backward partial sums share the (never zeroed) partials arena
+        statpart_count += (two ? 2 : 1) * (int64_t)bwd_parts * 2 * y1->C;
         const int64_t coef_off = bnbuf_count;
         bnbuf_count += (two ? 4 : 2) * (int64_t)y1->C;
         const int64_t M = y1->rows();
@@ -836,7 +895,7 @@ struct p3d_handle {
             if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; }
             if (two) { a.scale2 = bn2->scale; a.shift2 = bn2->shift; }
             a.z = out->p; a.ldz = out->ld;
-            if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
+            if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; a.seed_dev = c.seed_dev; }
             launch(c, kn_apply.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_apply(a, c.s); });
         };
         op.bwd = [=](const Ctx& c) {
@@ -852,15 +911,15 @@ struct p3d_handle {
             a.dz = out->g; a.lddz = out->ld;
             a.y1 = y1->p; a.ld1 = y1->ld; a.scale1 = bn1->scale; a.shift1 = bn1->shift; a.mean1 = bn1->mean; a.invstd1 = bn1->invstd;
             a.gamma1 = bn1->gamma->p; a.dgamma1 = bn1->gamma->g; a.dbeta1 = bn1->beta->g; a.batch1 = bn1->used_batch;
-            a.red1 = red_arena + red_off; a.coef1 = bnbuf + coef_off;
+            a.part1 = statpart_arena + red_off; a.nparts = bwd_parts; a.coef1 = bnbuf + coef_off;
             a.dy1 = y1->g; a.lddy1 = y1->ld; a.acc1 = 0;
             if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; a.dy2 = y2->g; a.lddy2 = y2->ld; a.acc2 = *f2; }
             if (two) {
                 a.scale2 = bn2->scale; a.shift2 = bn2->shift; a.mean2 = bn2->mean; a.invstd2 = bn2->invstd;
                 a.gamma2 = bn2->gamma->p; a.dgamma2 = bn2->gamma->g; a.dbeta2 = bn2->beta->g; a.batch2 = bn2->used_batch;
-                a.red2 = red_arena + red_off + (int64_t)P3D_STAT_REPLICAS * 2 * C; a.coef2 = bnbuf + coef_off + 2 * C;
+                a.part2 = statpart_arena + red_off + (int64_t)bwd_parts * 2 * C; a.coef2 = bnbuf + coef_off + 2 * C;
             }
-            if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
+            if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; a.seed_dev = c.seed_dev; }
             launch(c, kn_red.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_bwd_reduce(a, c.s); });
             launch(c, "bn_bwd_finalize_kernel", 0, 64.0 * C, [&]() { return p3d_bn_bwd_finalize(a, c.s); });
             launch(c, kn_bapply.c_str(), 0, tens * (y2 ? 5 : 3), [&]() { return p3d_bn_bwd_apply(a, c.s); });
@@ -973,7 +1032,7 @@ struct p3d_handle {
             a.dy1 = y1->g; a.lddy1 = y1->ld;
             if (mode == 6) { a.dy2 = cb->dout; a.lddy2 = C; a.acc2 = 0; }
             else if (y2) { a.dy2 = y2->g; a.lddy2 = y2->ld; a.acc2 = *f2; }
-            if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
+            if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; a.seed_dev = c.seed_dev; }
             a.eps = 1e-5f;
             a.dgamma1 = g1->gamma->g; a.dbeta1 = g1->beta->g;
             if (g2) { a.dgamma2 = g2->gamma->g; a.dbeta2 = g2->beta->g; }
@@ -1517,7 +1576,7 @@ struct p3d_handle {
                 memset(&a, 0, sizeof(a));
                 a.M = x->rows(); a.C = ch; a.r = r->p; a.ldr = r->ld; a.x = x->p; a.ldx = x->ld; a.gamma = gamma->p;
                 a.z = z->p; a.ldz = z->ld; a.dz = z->g; a.dr = r->g; a.dx = x->g; a.accx = *flx; a.dgamma = gamma->g;
-                if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; }
+                if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; a.seed_dev = c.seed_dev; }
                 return a;
             };
             const double fb = op.bytes, bb = op.bbytes;
@@ -1665,6 +1724,9 @@ struct p3d_handle {
             else p->p = flat_state + p->off;
         }
         stats_arena = dalloc<double>(stats_count);
+        statpart_arena = dalloc<float>(statpart_count);
+        d_seed = dalloc<unsigned long long>(1);
+        d_lr = dalloc<float>(1);
         red_arena = dalloc<double>(red_count);
         bnbuf = dalloc<float>(bnbuf_count);
         for (auto& f : late_bind) f();
@@ -1709,18 +1771,15 @@ struct p3d_handle {
         if (pos != 0) throw P3dError("gradient bucket walk does not reach offset 0");
     }
 
-    // One forward + backward over garbage data with the kernels' autotuners switched on: every distinct conv
-    // shape of the graph gets its tile / split decided by measurement before the zero arenas (which depend on
-    // those decisions) are laid out.  Parameters and moving statistics are not touched.
+    // One forward + backward over whatever the buffers hold: sizes the per-stream scratch of the K-sliced launches
+    // and sets the kernels' function attributes, so that nothing allocates later (a captured step graph must not).
+    // Parameters and moving statistics are not touched.
     void tune_plans() {
-        p3d_tune_begin(stream);
         Ctx c; c.training = true; c.s = stream;
-        HIPCHECK(hipMemsetAsync(stats_arena, 0, (size_t)stats_count * sizeof(double), c.s));
-        for (auto& op : ops) op.fwd(c);
-        HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), c.s));
-        for (int i = (int)ops.size() - 1; i >= 0; --i) ops[i].bwd(c);
+        run_forward(c);
+        run_loss(c);
+        run_backward(c, false);
         HIPCHECK(hipStreamSynchronize(c.s));
-        p3d_tune_end();
         HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
         HIPCHECK(hipStreamSynchronize(c.s));
     }
@@ -1771,7 +1830,7 @@ struct p3d_handle {
         fflush(stderr);
     }
     void run_forward(const Ctx& c) {
-        HIPCHECK(hipMemsetAsync(stats_arena, 0, (size_t)stats_count * sizeof(double), c.s));
+        if (stats_count) HIPCHECK(hipMemsetAsync(stats_arena, 0, (size_t)stats_count * sizeof(double), c.s));
         if (zf_bytes) HIPCHECK(hipMemsetAsync(zf, 0, zf_bytes, c.s));
         Ctx cz = c; cz.z0 = zf; cz.z1 = zf + zf_bytes;
         static const bool no_side_f = getenv("P3D_NO_SIDE_STREAM") != nullptr;
@@ -1793,35 +1852,44 @@ struct p3d_handle {
         c.side = (c.prof || no_side) ? nullptr : side_stream;      // per-launch profiling keeps one stream
         if (zb_bytes) HIPCHECK(hipMemsetAsync(zb, 0, zb_bytes, c.s));
         HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
-        HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), c.s));
+        if (red_count) HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), c.s));
         int64_t hi = n_train;                        // grads in [hi, n_train) are already handed to the comm stream
         size_t own_pos = own_sorted.size();
+        wq.clear(); wq_flushes = 0;
         for (int i = (int)ops.size() - 1; i >= 0; --i) {
             if (c.prof) c.prof->cur_op = ops[i].name;
             ops[i].bwd(c);
             debug_sync("bwd", ops[i], c);
-            if (allreduce && comm) {
+            if (allreduce && (comm || bucket_hook)) {
                 // gradients at flat offsets >= lo belong to ops i.. only, so they are final now
                 while (own_pos > 0 && own_sufmin[own_pos - 1] >= i) --own_pos;
                 const int64_t lo = own_pos < own_sorted.size() ? own_sorted[own_pos].first : n_train;
                 if ((hi > lo && hi - lo >= bucket_floats) || i == 0) {
                     const int64_t start = (i == 0) ? 0 : lo;
-                    if (hi > start) reduce_range(start, hi, c);
+                    flush_wgrads(c);                 // the bucket's queued filter gradients must be on the side stream first
+                    if (hi > start) reduce_range(start, hi, c, i);
                     hi = start;
                 }
             }
         }
+        flush_wgrads(c);
         if (c.side) {       // weight gradients must be complete before the optimiser (and the next step)
             HIPCHECK(hipEventRecord(ev_side_done, c.side));
             HIPCHECK(hipStreamWaitEvent(c.s, ev_side_done, 0));
         }
-        if (allreduce && comm) {
-            if (hi > 0) reduce_range(0, hi, c);
-            HIPCHECK(hipEventRecord(ev_comm_done, comm_stream));
-            HIPCHECK(hipStreamWaitEvent(c.s, ev_comm_done, 0));
+        if (allreduce && (comm || bucket_hook)) {
+            if (hi > 0) reduce_range(0, hi, c, 0);
+            if (comm) {
+                HIPCHECK(hipEventRecord(ev_comm_done, comm_stream));
+                HIPCHECK(hipStreamWaitEvent(c.s, ev_comm_done, 0));
+            }
         }
     }
-    void reduce_range(int64_t lo, int64_t hi, const Ctx& c) {
+    // audit hook (p3d_debug_bucket_audit): called in place of the collective with the range and the op whose backward
+    // had just run when the bucket was handed over
+    std::function<void(int64_t, int64_t, int)> bucket_hook;
+    void reduce_range(int64_t lo, int64_t hi, const Ctx& c, int after_op) {
+        if (bucket_hook) { bucket_hook(lo, hi, after_op); return; }
         HIPCHECK(hipEventRecord(ev_bucket, c.s));
         HIPCHECK(hipStreamWaitEvent(comm_stream, ev_bucket, 0));
         if (c.side) {       // the bucket's weight gradients were queued on the side stream
@@ -1830,11 +1898,76 @@ struct p3d_handle {
         }
         NCCLCHECK(ncclAllReduce(flat_g + lo, flat_g + lo, (size_t)(hi - lo), ncclFloat, ncclSum, comm, comm_stream));
     }
-    void run_adam(const Ctx& c) {
-        ++step;
-        const double t = (double)step;
-        const float lr_t = (float)(lr * std::sqrt(1.0 - std::pow((double)b2, t)) / (1.0 - std::pow((double)b1, t)));
-        launch(c, "adam_kernel", 0, 28.0 * n_train, [&]() { return p3d_adam(flat_p, flat_g, flat_m, flat_v, n_train, lr_t, b1, b2, eps, c.s); });
+    // tf.train.AdamOptimizer's bias-corrected step size lr * sqrt(1 - b2^t) / (1 - b1^t) for step t (train.py:168)
+    float adam_lr_t(int64_t t_step) const {
+        const double t = (double)t_step;
+        return (float)(lr * std::sqrt(1.0 - std::pow((double)b2, t)) / (1.0 - std::pow((double)b1, t)));
+    }
+    void run_adam(const Ctx& c) {        // c.lr_dev set: the step size comes from device memory (graph replay), `step` is the caller's
+        const float lr_t = c.lr_dev ? 0.f : adam_lr_t(++step);
+        launch(c, "adam_kernel", 0, 28.0 * n_train, [&]() { return p3d_adam(flat_p, flat_g, flat_m, flat_v, n_train, lr_t, c.lr_dev, b1, b2, eps, c.s); });
+    }
+
+    // ---- captured train step ------------------------------------------------------------------------
+    // One train step is ~1100 dependent launches on three streams; enqueueing them costs the host 6-11 ms, more
+    // than the GPU needs once the kernels are tuned.  The launch list is static, so it is captured ONCE into a
+    // hipGraph (per dropout rate / pointwise mode / communicator) and replayed; the two per-step scalars (dropout
+    // seed, Adam's bias-corrected step size) live in device memory and are written by a one-thread kernel ahead
+    // of each replay.  P3D_NO_GRAPH=1 keeps the eager launch list (debugging, per-launch profiling).
+    hipGraph_t step_graph = nullptr;
+    hipGraphExec_t step_exec = nullptr;
+    float graph_drop = -1.f; bool graph_f16 = false; ncclComm_t graph_comm = nullptr; float graph_b1 = 0, graph_b2 = 0, graph_eps = 0;
+    bool graph_disabled = false;
+    unsigned long long* d_seed = nullptr; float* d_lr = nullptr;
+    void drop_step_graph() {
+        if (step_exec) { hipGraphExecDestroy(step_exec); step_exec = nullptr; }
+        if (step_graph) { hipGraphDestroy(step_graph); step_graph = nullptr; }
+    }
+    bool graphs_enabled() {
+        static const bool off = getenv("P3D_NO_GRAPH") != nullptr || getenv("P3D_DEBUG_SYNC") != nullptr;
+        return !off && !graph_disabled;
+    }
+    void capture_step_graph(float drop) {
+        drop_step_graph();
+        Ctx c; c.training = true; c.drop = drop; c.seed = 0; c.seed_dev = d_seed; c.lr_dev = d_lr; c.update_moving = true; c.s = stream;
+        HIPCHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
+        try {
+            run_forward(c);
+            run_loss(c);
+            run_backward(c, true);
+            run_adam(c);
+        } catch (...) {
+            hipGraph_t g = nullptr;
+            hipStreamEndCapture(stream, &g);
+            if (g) hipGraphDestroy(g);
+            hipGetLastError();
+            throw;
+        }
+        HIPCHECK(hipStreamEndCapture(stream, &step_graph));
+        HIPCHECK(hipGraphInstantiate(&step_exec, step_graph, nullptr, nullptr, 0));
+        graph_drop = drop; graph_f16 = pointwise_f16; graph_comm = comm; graph_b1 = b1; graph_b2 = b2; graph_eps = eps;
+    }
+    void train_step_device(float drop, uint64_t seed) {
+        if (!graphs_enabled()) {
+            Ctx c; c.training = true; c.drop = drop; c.seed = seed; c.update_moving = true; c.s = stream;
+            run_forward(c); run_loss(c); run_backward(c, true); run_adam(c);
+            return;
+        }
+        if (!step_exec || graph_drop != drop || graph_f16 != pointwise_f16 || graph_comm != comm || graph_b1 != b1 || graph_b2 != b2 ||
+            graph_eps != eps) {
+            try {
+                capture_step_graph(drop);
+            } catch (const std::exception& e) {
+                // a runtime that cannot capture this launch list (e.g. a collective that refuses capture) still trains
+                fprintf(stderr, "[p3d] step graph capture failed (%s); using the eager launch list\n", e.what());
+                graph_disabled = true;
+                drop_step_graph();
+                train_step_device(drop, seed);
+                return;
+            }
+        }
+        HIPCHECK(p3d_set_step_scalars(d_seed, d_lr, seed, adam_lr_t(++step), stream));
+        HIPCHECK(hipGraphLaunch(step_exec, stream));
     }
 
     void upload(const float* x, const float* y) {
@@ -1857,10 +1990,12 @@ struct p3d_handle {
     }
 
     ~p3d_handle() {
+        drop_step_graph();
         if (comm) ncclCommDestroy(comm);
         if (ev_bucket) hipEventDestroy(ev_bucket);
         if (ev_comm_done) hipEventDestroy(ev_comm_done);
         for (hipEvent_t e : fork_events) hipEventDestroy(e);
+        for (hipEvent_t e : wq_events) hipEventDestroy(e);
         if (ev_side_done) hipEventDestroy(ev_side_done);
         if (ev_side_bucket) hipEventDestroy(ev_side_bucket);
         if (side_stream) hipStreamDestroy(side_stream);
@@ -1892,10 +2027,33 @@ void p3d_default_config(p3d_config* c) {
     c->device = 0; c->world_size = 1; c->rank = 0;
 }
 
+// Two HIP runtimes in one process (e.g. /opt/rocm's, which this library links, next to the copy a PyTorch wheel bundles)
+// end in heap corruption at exit.  Callers that bind the library by hand get the diagnosis here instead of there.
+static void refuse_two_hip_runtimes() {
+    FILE* f = fopen("/proc/self/maps", "r");
+    if (!f) return;
+    std::vector<std::string> seen;
+    char line[1024];
+    while (fgets(line, sizeof(line), f)) {
+        const char* p = strstr(line, "libamdhip64.so");
+        if (!p) continue;
+        const char* path = strchr(line, '/');
+        if (!path) continue;
+        std::string s(path);
+        while (!s.empty() && (s.back() == '\n' || s.back() == ' ')) s.pop_back();
+        if (std::find(seen.begin(), seen.end(), s) == seen.end()) seen.push_back(s);
+    }
+    fclose(f);
+    if (seen.size() > 1)
+        throw P3dError("two HIP runtimes are mapped into this process (" + seen[0] + " and " + seen[1] +
+                       "): load the one PyTorch bundles before libp3dhip.so (INTEGRATION.md, 'One HIP runtime per process')");
+}
+
 int p3d_create(const p3d_config* cfg, p3d_handle** out) {
     p3d_handle* h = nullptr;
     try {
         if (!cfg || !out) throw P3dError("null argument");
+        refuse_two_hip_runtimes();
         int ndev = 0;
         HIPCHECK(hipGetDeviceCount(&ndev));
         if (ndev <= 0) throw P3dError("no HIP device: libp3dhip has no CPU fallback");
@@ -1968,6 +2126,10 @@ int p3d_set_param(p3d_handle* h, const char* name, const float* host, int64_t co
     API_BEGIN
     Param* p = find_param(h, name, count);
     HIPCHECK(hipSetDevice(h->cfg.device));
+    // the handle's streams are non-blocking: nothing else orders this copy after a step that is still running
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipStreamSynchronize(h->side_stream));
+    HIPCHECK(hipStreamSynchronize(h->comm_stream));
     HIPCHECK(hipMemcpy(p->p, host, (size_t)count * 4, hipMemcpyHostToDevice));
     API_END
 }
@@ -2094,11 +2256,7 @@ int p3d_train_step_device(p3d_handle* h, float dropout_rate, uint64_t seed) {
     API_BEGIN
     if (!h) throw P3dError("null handle");
     HIPCHECK(hipSetDevice(h->cfg.device));
-    Ctx c; c.training = true; c.drop = dropout_rate; c.seed = seed; c.update_moving = true; c.s = h->stream;
-    h->run_forward(c);
-    h->run_loss(c);
-    h->run_backward(c, true);
-    h->run_adam(c);
+    h->train_step_device(dropout_rate, seed);
     API_END
 }
 
@@ -2107,11 +2265,7 @@ int p3d_train_step(p3d_handle* h, const float* x, const float* y, float dropout_
     if (!h || !x || !y) throw P3dError("null argument");
     HIPCHECK(hipSetDevice(h->cfg.device));
     h->upload(x, y);
-    Ctx c; c.training = true; c.drop = dropout_rate; c.seed = seed; c.update_moving = true; c.s = h->stream;
-    h->run_forward(c);
-    h->run_loss(c);
-    h->run_backward(c, true);
-    h->run_adam(c);
+    h->train_step_device(dropout_rate, seed);
     const float l = h->read_loss();
     if (loss) *loss = l;
     API_END
@@ -2185,7 +2339,7 @@ int p3d_block_forward(p3d_handle* h, int block_id, const float* in, int64_t in_c
     HIPCHECK(hipSetDevice(h->cfg.device));
     HIPCHECK(hipMemcpy2DAsync(a->p, (size_t)a->ld * 4, in, (size_t)a->C * 4, (size_t)a->C * 4, (size_t)a->rows(), hipMemcpyHostToDevice, h->stream));
     Ctx c; c.training = true; c.s = h->stream;
-    HIPCHECK(hipMemsetAsync(h->stats_arena, 0, (size_t)h->stats_count * sizeof(double), c.s));
+    if (h->stats_count) HIPCHECK(hipMemsetAsync(h->stats_arena, 0, (size_t)h->stats_count * sizeof(double), c.s));
     for (size_t i = it->second.op0; i < it->second.op1; ++i) h->ops[i].fwd(c);      // (no zero arena: ops zero what they slice)
     h->download_act(b, out);
     API_END
@@ -2224,6 +2378,60 @@ int p3d_profile_step(p3d_handle* h, float dropout_rate, uint64_t seed, p3d_op_ti
         g_err = e.what();
         return -1;
     }
+}
+
+int p3d_debug_bucket_audit(p3d_handle* h, float dropout_rate, uint64_t seed, int64_t bucket_floats, int64_t* lo, int64_t* hi,
+                           int32_t* after_op, int cap, int64_t* n_train, int64_t* stale) {
+    if (!h) { g_err = "null handle"; return -1; }
+    int count = 0;
+    try {
+        HIPCHECK(hipSetDevice(h->cfg.device));
+        if (bucket_floats < 1) throw P3dError("bucket size must be positive");
+        struct Snap { int64_t lo, hi; int op; std::vector<float> g; };
+        std::vector<Snap> snaps;
+        const int64_t saved = h->bucket_floats;
+        h->bucket_floats = bucket_floats;
+        h->bucket_hook = [&](int64_t l, int64_t u, int op) {
+            // everything the bucket's gradients depend on must already be QUEUED: wait for it, then look
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            HIPCHECK(hipStreamSynchronize(h->side_stream));
+            Snap s; s.lo = l; s.hi = u; s.op = op; s.g.resize((size_t)(u - l));
+            HIPCHECK(hipMemcpy(s.g.data(), h->flat_g + l, (size_t)(u - l) * 4, hipMemcpyDeviceToHost));
+            snaps.push_back(std::move(s));
+        };
+        try {
+            Ctx c; c.training = true; c.drop = dropout_rate; c.seed = seed; c.update_moving = false; c.s = h->stream;
+            h->run_forward(c);
+            h->run_loss(c);
+            h->run_backward(c, true);
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            HIPCHECK(hipStreamSynchronize(h->side_stream));
+        } catch (...) {
+            h->bucket_hook = nullptr; h->bucket_floats = saved;
+            throw;
+        }
+        h->bucket_hook = nullptr; h->bucket_floats = saved;
+        std::vector<float> fin((size_t)h->n_train);
+        HIPCHECK(hipMemcpy(fin.data(), h->flat_g, (size_t)h->n_train * 4, hipMemcpyDeviceToHost));
+        int64_t bad = 0;
+        for (auto& s : snaps) {
+            if (memcmp(s.g.data(), fin.data() + s.lo, s.g.size() * 4) != 0)
+                for (size_t i = 0; i < s.g.size(); ++i)
+                    if (memcmp(&s.g[i], &fin[(size_t)s.lo + i], 4) != 0) ++bad;
+            if (count < cap) {
+                if (lo) lo[count] = s.lo;
+                if (hi) hi[count] = s.hi;
+                if (after_op) after_op[count] = s.op;
+            }
+            ++count;
+        }
+        if (n_train) *n_train = h->n_train;
+        if (stale) *stale = bad;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+    return count;
 }
 
 int p3d_comm_unique_id(void* id_out) {
@@ -2276,7 +2484,7 @@ int p3d_op_conv3d(int device, const float* x, const int64_t xs[5], const float* 
     const int Cin = (int)xs[4], Cout = (int)ws[4];
     const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
     DevBuf dx(prod5(xs), x), dw(prod5(ws), w), dy(ny), db(Cout, bias);
-    IgemmArgs a = igemm_conv_forward(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, bias ? db.p : nullptr, nullptr, 0,
+    IgemmArgs a = igemm_conv_forward(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, bias ? db.p : nullptr, 0,
                                      is_stem_shape(xs, ws));
     ensure_zero_page();
     { Ctx c; std::vector<IgemmArgs> v{a}; run_igemm_group(c, v, dy.p, Cout, ny / Cout, Cout, false, nullptr); }
@@ -2293,7 +2501,7 @@ int p3d_op_conv3d_backprop_input(int device, const float* dyh, const float* w, c
     const int Cin = (int)xs[4], Cout = (int)ws[4];
     const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
     DevBuf dy(ny, dyh), dw(prod5(ws), w), dx(prod5(xs));
-    auto v = igemm_conv_input_side(g, (int)xs[0], dy.p, Cout, Cout, dx.p, Cin, Cin, dw.p, nullptr, nullptr, 0, true);
+    auto v = igemm_conv_input_side(g, (int)xs[0], dy.p, Cout, Cout, dx.p, Cin, Cin, dw.p, nullptr, 0, true);
     ensure_zero_page();
     { Ctx c; run_igemm_group(c, v, dx.p, Cin, prod5(xs) / Cin, Cin, false, nullptr); }
     dx.get(dxh, prod5(xs));
@@ -2327,7 +2535,7 @@ int p3d_op_conv3d_transpose(int device, const float* x, const int64_t xs[5], con
     if (ks[4] != Cin) throw P3dError("kernel Cin mismatch");
     const int64_t ny = xs[0] * g.I[0] * g.I[1] * g.I[2] * Cout;
     DevBuf dx(prod5(xs), x), dk(prod5(ks), kh), dy(ny), db(Cout, bias);
-    auto v = igemm_conv_input_side(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dk.p, bias ? db.p : nullptr, nullptr, 0, true);
+    auto v = igemm_conv_input_side(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dk.p, bias ? db.p : nullptr, 0, true);
     ensure_zero_page();
     { Ctx c; run_igemm_group(c, v, dy.p, Cout, ny / Cout, Cout, false, nullptr); }
     dy.get(y, ny);
@@ -2369,6 +2577,123 @@ int p3d_op_max_pool3d_grad(int device, const float* x, const int64_t xs[5], cons
     a.x = dx.p; a.dy = dy.p; a.dx = dg.p;
     HIPCHECK(p3d_maxpool_bwd(a, nullptr));
     dg.get(dxh, prod5(xs));
+    API_END
+}
+
+}  // extern "C"
+
+// ---- metrics / pre-processing entry points (metrics.hip) -------------------------------------------------------
+namespace {
+template <typename T>
+struct DevArr {
+    T* p = nullptr;
+    explicit DevArr(size_t n, const T* host = nullptr) {
+        HIPCHECK(hipMalloc((void**)&p, (n > 0 ? n : 1) * sizeof(T)));
+        if (host) HIPCHECK(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    }
+    ~DevArr() { hipFree(p); }
+    void get(T* host, size_t n) { HIPCHECK(hipDeviceSynchronize()); HIPCHECK(hipMemcpy(host, p, n * sizeof(T), hipMemcpyDeviceToHost)); }
+};
+void metric_args(int device, const void* a, const void* b, int n_maps, int n_pix, const void* out) {
+    if (!a || !b || !out) throw P3dError("null argument");
+    if (n_maps < 1 || n_pix < 1) throw P3dError("metrics need at least one map and one pixel");
+    int ndev = 0;
+    HIPCHECK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) throw P3dError("no HIP device: libp3dhip has no CPU fallback");
+    if (device < 0 || device >= ndev) throw P3dError("bad device ordinal");
+    HIPCHECK(hipSetDevice(device));
+}
+}  // namespace
+
+extern "C" {
+
+int p3d_metric_cc(int device, const float* a, const float* b, int n_maps, int n_pix, double* out) {
+    API_BEGIN
+    metric_args(device, a, b, n_maps, n_pix, out);
+    const size_t n = (size_t)n_maps * n_pix;
+    DevArr<float> da(n, a), db(n, b); DevArr<double> dout(n_maps);
+    HIPCHECK(p3d_metric_cc(da.p, db.p, n_maps, n_pix, dout.p, nullptr));
+    dout.get(out, n_maps);
+    API_END
+}
+int p3d_metric_sim(int device, const float* a, const float* b, int n_maps, int n_pix, double* out) {
+    API_BEGIN
+    metric_args(device, a, b, n_maps, n_pix, out);
+    const size_t n = (size_t)n_maps * n_pix;
+    DevArr<float> da(n, a), db(n, b); DevArr<double> dout(n_maps);
+    HIPCHECK(p3d_metric_sim(da.p, db.p, n_maps, n_pix, dout.p, nullptr));
+    dout.get(out, n_maps);
+    API_END
+}
+int p3d_metric_nss(int device, const float* sal, const float* fix, int n_maps, int n_pix, double* out) {
+    API_BEGIN
+    metric_args(device, sal, fix, n_maps, n_pix, out);
+    const size_t n = (size_t)n_maps * n_pix;
+    DevArr<float> da(n, sal), db(n, fix); DevArr<double> dout(n_maps);
+    HIPCHECK(p3d_metric_nss(da.p, db.p, n_maps, n_pix, dout.p, nullptr));
+    dout.get(out, n_maps);
+    API_END
+}
+int p3d_metric_auc_judd(int device, const float* sal, const float* fix, const float* jitter, int n_maps, int n_pix, double* out) {
+    API_BEGIN
+    metric_args(device, sal, fix, n_maps, n_pix, out);
+    const size_t n = (size_t)n_maps * n_pix;
+    const size_t pad = (size_t)p3d_metric_auc_pad(n_pix);
+    DevArr<float> da(n, sal), db(n, fix), dj(jitter ? n : 1, jitter), thr(pad * n_maps);
+    DevArr<int> cnt((pad + 1) * n_maps);
+    DevArr<double> dout(n_maps);
+    HIPCHECK(p3d_metric_auc_judd(da.p, db.p, jitter ? dj.p : nullptr, n_maps, n_pix, thr.p, cnt.p, dout.p, nullptr));
+    dout.get(out, n_maps);
+    API_END
+}
+int p3d_metric_auc_borji(int device, const float* sal, const float* fix, const int* rand_idx, int n_pix, int n_fix, int n_rep,
+                         double step_size, double* out) {
+    API_BEGIN
+    metric_args(device, sal, fix, 1, n_pix, out);
+    if (!rand_idx || n_rep < 1 || !(step_size > 0.0)) throw P3dError("AUC_Borji needs random indices, n_rep >= 1 and a positive step");
+    DevArr<float> da(n_pix, sal), db(n_pix, fix);
+    DevArr<int> fidx(n_pix), fcount(1);
+    HIPCHECK(p3d_metric_fix_index(db.p, n_pix, fidx.p, fcount.p, nullptr));
+    int have = 0;
+    fcount.get(&have, 1);
+    if (have == 0) { for (int i = 0; i < n_rep; ++i) out[i] = NAN; return 0; }      // "no fixation to predict"
+    if (have != n_fix) throw P3dError("AUC_Borji: n_fix = " + std::to_string(n_fix) + " but the fixation map has " + std::to_string(have) + " fixated pixels");
+    for (size_t i = 0; i < (size_t)n_fix * n_rep; ++i)
+        if (rand_idx[i] < 0 || rand_idx[i] >= n_pix) throw P3dError("AUC_Borji: random index out of range");
+    DevArr<int> dr((size_t)n_fix * n_rep, rand_idx);
+    DevArr<double> dout(n_rep);
+    HIPCHECK(p3d_metric_auc_borji(da.p, db.p, dr.p, n_pix, n_fix, n_rep, step_size, fidx.p, dout.p, nullptr));
+    dout.get(out, n_rep);
+    API_END
+}
+int p3d_mapf_frames(int device, const unsigned char* bgr, int n, int H0, int W0, const float mean_rgb[3], int H, int W, float* out) {
+    API_BEGIN
+    metric_args(device, bgr, mean_rgb, 1, 1, out);
+    if (n < 1 || H0 < 1 || W0 < 1 || H < 1 || W < 1) throw P3dError("mapf: empty frame");
+    DevArr<unsigned char> src((size_t)n * H0 * W0 * 3, bgr);
+    DevArr<float> dst((size_t)n * H * W * 3);
+    HIPCHECK(p3d_mapf_frames(src.p, n, H0, W0, dst.p, H, W, mean_rgb, nullptr));
+    dst.get(out, (size_t)n * H * W * 3);
+    API_END
+}
+int p3d_mapf_density(int device, const unsigned char* grey, int n, int H0, int W0, int H, int W, float* out) {
+    API_BEGIN
+    metric_args(device, grey, grey, 1, 1, out);
+    if (n < 1 || H0 < 1 || W0 < 1 || H < 1 || W < 1) throw P3dError("mapf: empty frame");
+    DevArr<unsigned char> src((size_t)n * H0 * W0, grey);
+    DevArr<float> dst((size_t)n * H * W);
+    HIPCHECK(p3d_mapf_density(src.p, n, H0, W0, dst.p, H, W, nullptr));
+    dst.get(out, (size_t)n * H * W);
+    API_END
+}
+
+int p3d_shutdown(void) {
+    API_BEGIN
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return 0;
+    hipDeviceSynchronize();
+    p3d_release_scratch();
+    if (g_zero_page) { hipFree((void*)g_zero_page); g_zero_page = nullptr; }
     API_END
 }
 

@@ -16,7 +16,8 @@
 #include <stdint.h>
 
 #define P3D_MAX_TAPS 27
-#define P3D_STAT_REPLICAS 16   // per-channel accumulators are replicated to spread same-address atomics
+#define P3D_WGRAD_GROUP 6     // weight-gradient problems one grouped launch can carry (kernel-argument space)
+#define P3D_STAT_REPLICAS 16   // per-channel accumulators are replicated to spread same-address atomics (backward reductions, GN)
 
 struct P3dTap {
     int16_t dd, dh, dw;   // gathered coordinate = g*is + d{d,h,w}
@@ -39,7 +40,11 @@ struct IgemmArgs {
     const float* w;       // weights: slab widx is [K][Nc] (wT=0) or [Nc][K] (wT=1)
     int wT;
     const float* bias;    // [Nc] or null
-    double* stats;        // [P3D_STAT_REPLICAS][Nc][2] (sum, sum of squares) of the stored values, or null
+    // BatchNorm statistics epilogue: per-(output tile row, channel) partial (sum, sum of squares) of the stored values,
+    // written with plain stores to statpart[(stat_base + m_tile) * Nc + col][2] -- no atomics, so the statistics (and
+    // everything downstream) are bit-reproducible; p3d_bn_finalize folds the partials in a fixed order.  Null: none.
+    float* statpart;
+    int stat_base;
     int accum;            // 1: Y += result (gradient accumulation)
     int sigmoid;          // 1: store 1/(1+exp(-v)) (unused by the generic path today)
     // stem mode (firstconv1, p3d.py:172): the W axis and the 3 input channels are
@@ -48,7 +53,12 @@ struct IgemmArgs {
     int stem_wstep;       // floats advanced per output column (sw*Cin)
     int stem_wpad;        // floats of left padding (pad_w*Cin)
     const float* zeros;   // >= 128 B of zeros in device memory (source for padded / tail lanes; igemm2 only)
-    int exp;              // tuning experiments only (tools/tune_igemm.py): 1 skip main loop, 2 skip epilogue
+    // K-slicing (filled by the launcher from the plan): slice s of a tile stores its partial tile to
+    // slab[(tile * nsplit + s) * BM*BN], the block whose arrival ticket is the last one sums the slices in slice order
+    // (bit-reproducible, unlike atomics), applies bias / accumulate / statistics and writes the output.
+    float* slab; unsigned* cnt; int nsplit;
+    int xmap;             // 1: 1-D grid, slice = block % nsplit, tile = block / nsplit (with nsplit = 8 a slice's tiles
+                          // share one XCD's L2 under round-robin dispatch: speed only)
     int f16;              // 1: round the operand fragments to fp16 and use the fp16 MFMA (fp32 accumulate); pointwise convs of configs[4]
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
@@ -57,8 +67,18 @@ struct IgemmArgs {
 // Tile and split-K choice of the pipelined kernel (conv_igemm2.hip)
 struct P3dIgemmPlan {
     int bm = 64, bn = 64, splits = 1;
+    int xmap = 0;
     const char* name = "";
 };
+// number of output-tile rows (= statistics partials) a launch with this plan produces
+inline int p3d_igemm2_mtiles(const IgemmArgs& a, const P3dIgemmPlan& pl) {
+    const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
+    return (int)((M + pl.bm - 1) / pl.bm);
+}
+// Per-stream scratch for K-sliced launches (partial tiles + arrival counters).  Launches on one stream run in order, so
+// they share it; the buffers only grow, and an outgrown buffer stays allocated (captured graphs may still name it).
+hipError_t p3d_stream_scratch(hipStream_t s, size_t slab_floats, size_t counters, float** slab, unsigned** cnt);
+void p3d_release_scratch();     // frees every scratch buffer (process shutdown; no launch may be in flight)
 
 // Weight-gradient launch: dW[widx][k][n] += sum_m Xg[m+tap, k] * dY[m, n]
 struct WgradArgs {
@@ -68,9 +88,9 @@ struct WgradArgs {
     int isd, ish, isw;
     const float* dy;      // dense operand
     int ldy, Nc;
-    float* dw;            // [slab][K][Nc], accumulated with float atomics
+    float* dw;            // [slab][K][Nc]; the launch ADDS the gradient to it (single writer per element: plain read-modify-write)
     float* dbias;         // [Nc] or null (column sums of dy, added by tap 0 / k-tile 0 blocks)
-    int ksplit;           // number of M-range splits (gridDim.y)
+    int ksplit;           // (chosen by the launcher)
     int stem_wfloats, stem_wstep, stem_wpad;
     const float* zeros;   // zero page (wgrad2 only)
     int ntaps;
@@ -89,24 +109,29 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split);
 void p3d_tune_begin(hipStream_t s);
 void p3d_tune_end();
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipStream_t s);
+void p3d_igemm2_override(int tile, int splits, int xmap);   // tools/micro sweeps: -1 / 0 / -1 = no override
 const char* p3d_igemm_variant(const IgemmArgs& a);     // kernel symbol the launcher will pick
 const char* p3d_wgrad_variant(const WgradArgs& a);
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s);
+hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s);   // up to P3D_WGRAD_GROUP problems, one launch
 const char* p3d_wgrad2_variant(const WgradArgs& a);
 
 // ---- BatchNorm (tf.layers.batch_normalization, rank-5, eps 1e-3) ------------------------------
 struct BnParams {          // device pointers, all [C]
     const float* gamma; const float* beta;
     float* moving_mean; float* moving_var;
-    double* stats;         // [P3D_STAT_REPLICAS][C][2] sum, sumsq filled by the producer's epilogue
+    const float* statpart; // [nparts][C][2] partial (sum, sumsq) written by the producer's epilogue or p3d_bn_stats
+    int nparts;
     float* scale; float* shift;      // y_hat = scale*y + shift
     float* mean; float* invstd;      // saved for backward
     int C;
 };
 // use_batch: statistics from `stats` over M rows, else moving stats.  update_moving: momentum 0.99 update.
 hipError_t p3d_bn_finalize(const BnParams& bn, long M, int use_batch, int update_moving, float eps, hipStream_t s);
-// stats[c] += (sum, sum of squares) over the M rows of y (for producers that cannot do it in their epilogue)
-hipError_t p3d_bn_stats(const float* y, int ld, long M, int C, double* stats, hipStream_t s);
+// statpart[b][c] = (sum, sum of squares) over block b's rows of y, b < p3d_bn_stats_parts(M, C)
+// (for producers that cannot do it in their epilogue)
+int p3d_bn_stats_parts(long M, int C);
+hipError_t p3d_bn_stats(const float* y, int ld, long M, int C, float* statpart, hipStream_t s);
 
 // Fused normalise/activate/add passes.  Modes (reference p3d.py lines in brackets):
 //  0: z = relu(bn1(y1))                         [58-59, 88+97, 173-174, 201-202]
@@ -122,12 +147,12 @@ struct BnApplyArgs {
     float* z; int ldz;
     float drop_scale;      // >0: inverted dropout with this keep scale (p3d.py:214), keyed by seed
     float drop_rate; unsigned long long seed;
+    const unsigned long long* seed_dev;   // non-null: the seed is read from device memory (captured step graphs)
 };
 hipError_t p3d_bn_apply(const BnApplyArgs& a, hipStream_t s);
 
-// Backward of the passes above.  Pass 1 reduces per channel sum(dz') and sum(dz' * xhat) into
-// red1/red2 ([P3D_STAT_REPLICAS][C][2] doubles, zeroed by the caller); a finalize pass folds the
-// replicas into coef1/coef2 ([C][2] floats: the two sums / M) and the parameter gradients; pass 2
+// Backward of the passes above.  Pass 1 reduces per channel sum(dz') and sum(dz' * xhat) into per-block
+// partials part1/part2; a finalize pass folds them in block order into coef1/coef2 ([C][2] floats: the two sums / M) and the parameter gradients; pass 2
 // writes the input gradients.
 struct BnBwdArgs {
     int mode;
@@ -136,14 +161,16 @@ struct BnBwdArgs {
     const float* y1; int ld1; const float* scale1; const float* shift1; const float* mean1; const float* invstd1;
     const float* y2; int ld2; const float* scale2; const float* shift2; const float* mean2; const float* invstd2;
     const float* gamma1; const float* gamma2;
-    double* red1; double* red2;
+    float* part1; float* part2;      // per-block partial sums [nparts][C][2] (plain stores: no atomics), nparts = p3d_bn_bwd_parts(M, C)
+    int nparts;
     float* coef1; float* coef2;
     float* dgamma1; float* dbeta1; float* dgamma2; float* dbeta2;      // parameter grads (written)
     int batch1, batch2;    // 1: batch statistics were used (full BN backward), 0: inference BN
     float* dy1; int lddy1; int acc1;
     float* dy2; int lddy2; int acc2;      // dy2 doubles as dr (modes 1,4)
-    float drop_scale; float drop_rate; unsigned long long seed;
+    float drop_scale; float drop_rate; unsigned long long seed; const unsigned long long* seed_dev;
 };
+int p3d_bn_bwd_parts(long M, int C);
 hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
 hipError_t p3d_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s);
 hipError_t p3d_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);
@@ -184,9 +211,10 @@ struct GnApplyArgs {
     const float* dz;                             // backward: gradient of z (same stride as z)
     float* dy1; int lddy1;
     float* dy2; int lddy2; int acc2;             // mode 3: GN2 input grad; 1,4: residual grad; 6: grad of the CBAM output
-    float drop_scale; float drop_rate; unsigned long long seed;
+    float drop_scale; float drop_rate; unsigned long long seed; const unsigned long long* seed_dev;
     // one-launch path for small tensors (p3d_gn_small_*): epsilon, and where the parameter gradients are ADDED
     float eps; float* dgamma1; float* dbeta1; float* dgamma2; float* dbeta2;
+    float* part; unsigned* counters;             // backward partial sums + arrival counters (set by the launchers)
 };
 bool p3d_gn_small_ok(int R, int C, int G);       // a (sample, group) slab fits one block's registers
 hipError_t p3d_gn_small_fwd(const GnApplyArgs& a, hipStream_t s);    // stats + tables + normalise/activate in one launch
@@ -221,6 +249,7 @@ struct CbamArgs {
     float* dh;                                   // [N][2][Ch] gradients of the hidden activations (avg, max branch)
     float* dx; int lddx; int accx;               // gradient of x
     float* dk0; float* db0; float* dk1; float* db1; float* dk7;
+    float* k7part; unsigned* k7counter;          // dK7 partials [blocks][343][2] + arrival counter (set by the launcher)
 };
 hipError_t p3d_cbam_forward(const CbamArgs& a, hipStream_t s);
 hipError_t p3d_cbam_backward(const CbamArgs& a, hipStream_t s);
@@ -234,9 +263,10 @@ struct AttnMixArgs {                 // z = r * gamma + x  (utils/network.py:191
     const float* x; int ldx;         // the block's input
     const float* gamma;              // [1]
     float* z; int ldz;
-    float drop_scale; float drop_rate; unsigned long long seed;
+    float drop_scale; float drop_rate; unsigned long long seed; const unsigned long long* seed_dev;
     // backward
     const float* dz; float* dr; float* dx; int accx; float* dgamma;
+    float* part; unsigned* counter;  // dgamma partials per block + arrival counter (set by the launcher)
 };
 hipError_t p3d_attn_mix_fwd(const AttnMixArgs& a, hipStream_t s);
 hipError_t p3d_attn_mix_bwd(const AttnMixArgs& a, hipStream_t s);
@@ -269,6 +299,7 @@ struct HeadArgs {
     float* logits; float* pred;            // pre- and post-sigmoid
     int sigmoid;                           // 0: pred = logits (p3d_concat head, p3d.py:275)
     const float* dlogits; float* dx; float* dk; float* dbias;
+    float* part; unsigned* counter;        // filter-gradient partials [blocks][28][C] + arrival counter (set by the launcher)
 };
 hipError_t p3d_head_fwd(const HeadArgs& a, hipStream_t s);
 hipError_t p3d_head_bwd_input(const HeadArgs& a, hipStream_t s);    // dx written
@@ -284,8 +315,25 @@ hipError_t p3d_smooth_l1(const float* pred, const float* target, long n, double*
                          float* dlogits, int through_sigmoid, hipStream_t s);
 
 // ---- Adam (tf.train.AdamOptimizer, epsilon-hat form; train.py:168) ------------------------------
-hipError_t p3d_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
+// lr_dev non-null: the bias-corrected step size is read from device memory (captured step graphs), lr_t is ignored
+hipError_t p3d_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, const float* lr_dev, float b1, float b2,
                     float eps, hipStream_t s);
+// per-step scalars of a captured train step: scal[0..1] = dropout seed (64 bit), scal[2] = Adam's bias-corrected step size
+hipError_t p3d_set_step_scalars(unsigned long long* seed_dst, float* lr_dst, unsigned long long seed, float lr_t, hipStream_t s);
+
+// ---- saliency metrics + frame pre-processing (metrics.hip; utils/metrics.py:25-287, dataflow.py:187-216) ------
+hipError_t p3d_metric_cc(const float* a, const float* b, int n_maps, int n_pix, double* out, hipStream_t s);
+hipError_t p3d_metric_sim(const float* a, const float* b, int n_maps, int n_pix, double* out, hipStream_t s);
+hipError_t p3d_metric_nss(const float* sal, const float* fix, int n_maps, int n_pix, double* out, hipStream_t s);
+int p3d_metric_auc_pad(int n_pix);      // scratch per map: pad floats (thresholds) + pad + 1 ints (counters)
+hipError_t p3d_metric_auc_judd(const float* sal, const float* fix, const float* jitter, int n_maps, int n_pix, float* thr_scratch,
+                               int* cnt_scratch, double* out, hipStream_t s);
+hipError_t p3d_metric_fix_index(const float* fix, int n_pix, int* idx, int* count, hipStream_t s);
+hipError_t p3d_metric_auc_borji(const float* sal, const float* fix, const int* rand_idx, int n_pix, int n_fix, int n_rep, double step,
+                                const int* fix_idx, double* out_per_rep, hipStream_t s);
+hipError_t p3d_mapf_frames(const unsigned char* bgr, int n_frames, int H0, int W0, float* dst, int H, int W, const float mean_rgb[3],
+                           hipStream_t s);
+hipError_t p3d_mapf_density(const unsigned char* grey, int n_frames, int H0, int W0, float* dst, int H, int W, hipStream_t s);
 
 // ---- misc ---------------------------------------------------------------------------------------
 hipError_t p3d_add_inplace(float* dst, int lddst, const float* src, int ldsrc, long M, int C, hipStream_t s);

@@ -31,6 +31,7 @@ class P3DSession:
         self.cfg.device, self.cfg.world_size, self.cfg.rank = device, world_size, rank
         self._h = C.c_void_p()
         check(lib().p3d_create(C.byref(self.cfg), C.byref(self._h)))
+        _lib.register_session(self)
         self.x_shape = (batch, frames, height, width, 3)
         self.y_shape = (batch, frames, height, width)
         self.pred_shape = (batch, frames, height, width, 1)
@@ -174,6 +175,17 @@ class P3DSession:
     # ---- device-resident stepping (bench) ------------------------------------------------------
     def upload(self, x, y):
         check(lib().p3d_upload_inputs(self._h, fptr(self._x(x)), fptr(self._y(y)) if y is not None else None))
+
+    def bucket_audit(self, bucket_floats, dropout=0.0, seed=0, cap=4096):
+        """Test hook for the bucketed gradient hand-over of data-parallel training (include/p3d_hip.h,
+        p3d_debug_bucket_audit): ([(lo, hi, after_op)], n_train, stale)."""
+        lo = (C.c_int64 * cap)(); hi = (C.c_int64 * cap)(); op = (C.c_int32 * cap)()
+        n_train = C.c_int64(); stale = C.c_int64()
+        n = lib().p3d_debug_bucket_audit(self._h, float(dropout), seed, int(bucket_floats), lo, hi, op, cap, C.byref(n_train),
+                                         C.byref(stale))
+        if n < 0:
+            check(n)
+        return [(lo[i], hi[i], op[i]) for i in range(min(n, cap))], n_train.value, stale.value
 
     def train_step_device(self, dropout=0.0, seed=0):
         check(lib().p3d_train_step_device(self._h, float(dropout), seed))

@@ -368,22 +368,14 @@ def test_gn_cbam_forward_backward(ci, head, flip_allowance):
     l32, _, g32, _ = p3d_gn.loss_and_grads(dict(p32), x, y, 0.0, True, cfg, np.float32, head=head)
     scale = np.median([np.linalg.norm(v) for v in g64.values()])
     floor = 1e-2 * scale
-    # CBAM routes gradients through arg-max selections (over positions and over channels).  At this size one
-    # near-tie resolves either way depending on the order the split-K atomics happen to add in, and the other
-    # branch moves every upstream gradient by 0.5-1 % (tools/gn_flip_probe.py: ~1 run in 5, always the same
-    # two outcomes).  Both are valid fp32 results, so: every run must be within 3e-2 of the fp64 oracle, and
-    # some run out of at most six must be within the tight fp32-noise bound on every tensor.
-    tight = False
-    for attempt in range(6):
-        loss, pred = s.backward(x, y, 0.0)
-        assert abs(loss - l64) < 1e-5 * abs(l64)
-        errs = {n: rel_l2(s.get_grad(n), w, floor) for n, w in g64.items()}
-        for n, e in errs.items():
-            assert e <= 3e-2, (attempt, n, e)
-        if all(e <= 5 * rel_l2(g32[n], g64[n], floor) + 2e-3 + flip_allowance for n, e in errs.items()):
-            tight = True
-            break
-    assert tight, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # CBAM routes gradients through arg-max selections (over positions and over channels): a near-tie that resolved
+    # the other way would move every upstream gradient by 0.5-1 %.  The HIP path folds every cross-block sum in a fixed
+    # order (tests/test_gpu_determinism.py), so ONE run decides, and it must meet the fp32-noise bound on every tensor.
+    loss, pred = s.backward(x, y, 0.0)
+    assert abs(loss - l64) < 1e-5 * abs(l64)
+    errs = {n: rel_l2(s.get_grad(n), w, floor) for n, w in g64.items()}
+    bad = {n: e for n, e in errs.items() if e > 5 * rel_l2(g32[n], g64[n], floor) + 2e-3 + flip_allowance}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
     s.close()
 
 
