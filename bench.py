@@ -45,13 +45,42 @@ def kernel_table(recs):
     return rows
 
 
+def per_layer_table(recs):
+    """Per reference layer (stem, pool*, bottleneck i, deconv j, head, loss, optimiser): device time,
+    algorithmic FLOPs and bytes of its launches (forward + backward), the roofline that bounds it and the fraction reached.
+    A grouped filter-gradient launch is booked on the layer whose backward flushed it."""
+    import re
+    order, agg = [], {}
+    for r in recs:
+        name = r["name"]
+        layer = name.split("/")[0] if name else "op"
+        layer = re.sub(r"_bn$", "", layer)
+        if layer not in agg:
+            order.append(layer)
+            agg[layer] = dict(layer=layer, launches=0, ms=0.0, flops=0.0, bytes=0.0)
+        a = agg[layer]
+        a["launches"] += 1; a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]
+    rows = []
+    ridge = PEAK_FP32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    for layer in order:
+        a = agg[layer]
+        t = max(a["ms"], 1e-9) * 1e-3
+        tf, gb = a["flops"] / t / 1e12, a["bytes"] / t / 1e9
+        bound = "mfma" if a["flops"] / max(a["bytes"], 1.0) >= ridge else "hbm"
+        # time the layer would need at both roofs; the larger one bounds it
+        t_roof = max(a["flops"] / (PEAK_FP32_TFLOPS * 1e12), a["bytes"] / (PEAK_HBM_GBS * 1e9))
+        rows.append(dict(layer=layer, launches=a["launches"], ms=round(a["ms"], 4), gflop=round(a["flops"] / 1e9, 3), mbytes=round(a["bytes"] / 1e6, 3),
+                         tflops=round(tf, 2), gbs=round(gb, 1), bound=bound, frac=round(t_roof / t, 4)))
+    return rows
+
+
 def measured_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json), or None."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
-            k = json.load(open(f))["kernels"].get(kernel)
+            k = json.load(open(f))["kernels"].get(kernel.replace("(grouped)", ""))
         except Exception:
             k = None
         if k:
@@ -133,6 +162,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--dump-launches", default=None, help="write every launch record of the profiled step to this CSV")
+    ap.add_argument("--per-layer", default=None, help="write the per-layer roofline table of the profiled step to this CSV")
     args = ap.parse_args()
 
     from sap3d_tensorflow_amd.dp import Plane
@@ -184,6 +214,13 @@ def main():
                 f.write("op,kernel,phase,ms,flops,bytes\n")
                 for r in recs:
                     f.write("%s,\"%s\",%d,%.5f,%.0f,%.0f\n" % (r["name"], r["kernel"], r["phase"], r["ms"], r["flops"], r["bytes"]))
+        if args.per_layer:
+            rows_l = per_layer_table(recs)
+            with open(args.per_layer, "w") as f:
+                f.write("layer,launches,ms,gflop,mbytes,tflops,gbs,bound,frac_of_roofline\n")
+                for r in rows_l:
+                    f.write("%s,%d,%.4f,%.3f,%.3f,%.2f,%.1f,%s,%.4f\n" % (r["layer"], r["launches"], r["ms"], r["gflop"], r["mbytes"], r["tflops"],
+                                                                          r["gbs"], r["bound"], r["frac"]))
         out = {
             "metric": "clips/s (16x112x112 fwd+bwd)", "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),

@@ -3,7 +3,7 @@
 
 For every video: a 16-frame queue slides by ONE frame (gen_pred.py:100-134); the first window emits all 16 maps,
 every later window only its last map (gen_pred.py:154-168); frames are normalised like gen_pred.py:117-121
-((RGB - [90,102,98]) / 255 after resizing to 112x112).  The reference decodes JPEG folders with cv2 and writes
+((RGB - [90,102,98]) / 255 after resizing to 112x112) by the fused GPU pass of sap3d_tensorflow_amd.dataflow.  The reference decodes JPEG folders with cv2 and writes
 960x1080 JPEGs; cv2 is outside this path, so a video here is a .npy array [F,H,W,3] uint8 RGB and the maps come
 back as a float32 array [F,112,112].  Stride-1 windows are batched (`--batch`) instead of run one by one:
 `p3d_predict_windows` gives every window the result of its own batch-of-1 run (the backbone BatchNorm uses batch
@@ -18,24 +18,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-MEAN = np.array([90, 102, 98], np.float32)          # gen_pred.py:40-41
-
-
-def resize_bilinear(frames, size=112):
-    """[F,H,W,3] -> [F,size,size,3], half-pixel-centre bilinear (cv2.INTER_LINEAR's sampling)."""
-    F, H, W, _ = frames.shape
-    ys = np.clip((np.arange(size) + 0.5) * H / size - 0.5, 0, H - 1)
-    xs = np.clip((np.arange(size) + 0.5) * W / size - 0.5, 0, W - 1)
-    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
-    y1, x1 = np.minimum(y0 + 1, H - 1), np.minimum(x0 + 1, W - 1)
-    wy, wx = (ys - y0)[None, :, None, None], (xs - x0)[None, None, :, None]
-    a = frames[:, y0][:, :, x0]; b = frames[:, y0][:, :, x1]
-    c = frames[:, y1][:, :, x0]; d = frames[:, y1][:, :, x1]
-    return (a * (1 - wy) * (1 - wx) + b * (1 - wy) * wx + c * wy * (1 - wx) + d * wy * wx).astype(np.float32)
-
-
-def preprocess(video_u8):
-    return (resize_bilinear(video_u8.astype(np.float32) - MEAN) / 255.0).astype(np.float32)
+def preprocess(video_u8, device=0):
+    """gen_pred.py:117-121 per frame (RGB - mean, resize to 112, / 255) as one fused GPU pass (csrc/metrics.hip);
+    the kernel takes cv2's BGR order, the .npy videos here are RGB."""
+    from sap3d_tensorflow_amd import dataflow
+    return dataflow.mapf_frames(np.ascontiguousarray(video_u8[..., ::-1]), 112, device=device)
 
 
 def predict_video(sess, frames, batch):
@@ -59,16 +46,20 @@ def predict_video(sess, frames, batch):
 
 def main():
     p = argparse.ArgumentParser()
-    p.add_argument("--model", type=str, default="", help="checkpoint .npz (TF variable names)")
+    p.add_argument("--model", type=str, default="", help="checkpoint: a directory with a TF `checkpoint` state file (gen_pred.py:57-64), "
+                   "a TF bundle prefix, or an .npz keyed by TF variable names")
+    p.add_argument("--structure", type=str, default="unet++ds",
+                   help="graph to build: unet++ds = p3d_unetplusplus_ds, the buildable form of what gen_pred.py:46 constructs; or unet, "
+                        "concat, unet++nonsa, gn_p3d, gn_p3d_concat, gn_p3d_decoder")
     p.add_argument("--videos", type=str, required=True, help="folder with <name>.npy videos [F,H,W,3] uint8 RGB")
     p.add_argument("--out", type=str, default="pred")
     p.add_argument("--batch", type=int, default=8)
     p.add_argument("--gpu", type=str, default="0")
     args = p.parse_args()
     from sap3d_tensorflow_amd import P3DSession
-    sess = P3DSession("unet", batch=args.batch, device=int(args.gpu), seed=0)
+    sess = P3DSession(args.structure, batch=args.batch, device=int(args.gpu), seed=0)
     if args.model:
-        sess.load(dict(np.load(args.model)))
+        sess.restore(args.model)
     os.makedirs(args.out, exist_ok=True)
     for path in sorted(glob.glob(os.path.join(args.videos, "*.npy"))):
         sal = predict_video(sess, preprocess(np.load(path)), args.batch)

@@ -4,9 +4,13 @@
 Same flags (train.py:21-45), same step semantics (train.py:217-218: dropout 0.5, training=True, Adam lr,
 Smooth-L1 sum), same periodic eval forward (train.py:225-226) and checkpoint cadence (train.py:266-267).  The
 dataset loaders (dataflow.py, tensorpack, cv2) are out of scope: clips come either from
-`--data clips.npz` (arrays x [N,16,112,112,3] already normalised like dataflow.py:204-208, y [N,16,112,112]) or
-are synthetic with the loader's value law.  Checkpoints are .npz files keyed by the TF variable names of
-train.py:180-185 (trainables + BN moving statistics)."""
+`--data clips.npz` (arrays x [N,16,112,112,3] already normalised like dataflow.py:204-208, y [N,16,112,112]; raw uint8
+frames go through sap3d_tensorflow_amd.dataflow.mapf_frames first) or are synthetic with the loader's value law.
+Checkpoints are TensorFlow-1.x V2 bundles `model/<info>/p3d_<step>.ckpt.*` with a `checkpoint` state file, keyed by the
+TF variable names of train.py:180-185 (trainables + BN moving statistics): the files the reference's Saver writes and
+restores (sap3d_tensorflow_amd/tf_checkpoint.py); `--pretrain` takes such a directory, a bundle prefix, or an .npz.
+Every `--validiter` steps the validation pass of train.py:243-264 runs: eval forward over the validation clips, CC / SIM /
+AUC_Judd of the LAST frame of every clip (GPU kernels, sap3d_tensorflow_amd.metrics), NaNs dropped, means printed."""
 import argparse
 import datetime
 import os
@@ -30,7 +34,8 @@ def get_arguments():
     p.add_argument("--lr", type=float, default=1e-4)
     p.add_argument("--epoch", type=int, default=1)
     p.add_argument("--gpu", type=str, default="0")
-    p.add_argument("--pretrain", type=str, default="", help="checkpoint .npz to resume from (train.py:204-210)")
+    p.add_argument("--pretrain", type=str, default="", help="checkpoint to resume from (train.py:204-210): a directory with a `checkpoint` "
+                   "state file (as the reference takes, ./model/<pretrain>/), a TF bundle prefix, or an .npz")
     p.add_argument("--saveiter", type=int, default=1000)
     p.add_argument("--validiter", type=int, default=1000)
     p.add_argument("--plotiter", type=int, default=1000)
@@ -44,6 +49,7 @@ def get_arguments():
     p.add_argument("--imagesize", type=int, nargs=2, default=(112, 112), help="clip height width (train.py:34)")
     p.add_argument("--data", type=str, default="", help="npz with x, y; empty = synthetic clips")
     p.add_argument("--steps", type=int, default=20, help="steps per epoch when synthetic")
+    p.add_argument("--validclips", type=int, default=4, help="validation batches per validation pass when synthetic")
     return p.parse_args()
 
 
@@ -61,6 +67,39 @@ def batches(args, rng):
         for s in range(args.epoch * args.steps):
             shape = (args.batch, args.videolength, args.imagesize[0], args.imagesize[1])
             yield law.synthetic_clip(s, shape + (3,)), law.synthetic_target(10_000 + s, shape)
+
+
+def validation_batches(args):
+    """gt_df of train.py:110-121: the held-out clips (the last 1 - trainingprops share of --data), or synthetic ones."""
+    from sap3d_tensorflow_amd import synthetic as law
+    if args.data:
+        d = np.load(args.data)
+        x, y = d["x"].astype(np.float32), d["y"].astype(np.float32)
+        first = min(int(len(x) * args.trainingprops), len(x) - args.batch)
+        for i in range(max(first, 0), len(x) - args.batch + 1, args.batch):
+            yield x[i:i + args.batch], y[i:i + args.batch]
+    else:
+        for s in range(args.validclips):
+            shape = (args.batch, args.videolength, args.imagesize[0], args.imagesize[1])
+            yield law.synthetic_clip(500_000 + s, shape + (3,)), law.synthetic_target(600_000 + s, shape)
+
+
+def validate(sess, args, step):
+    """train.py:243-264: CC, SIM, AUC_Judd between the last predicted frame and the last ground-truth frame of every
+    validation clip; NaNs (no fixation, flat map) are dropped before averaging."""
+    from sap3d_tensorflow_amd import metrics
+    print("Doing validation...")
+    preds, gts = [], []
+    for xs, ys in validation_batches(args):
+        image0 = sess.forward(xs, dropout=0.0, training=False)[..., 0]              # train.py:250-251
+        preds.append(image0[:, -1]); gts.append(ys[:, -1])                          # prediction[-1], ground_truth[-1]
+    if not preds:
+        return None
+    p, g = np.concatenate(preds), np.concatenate(gts)
+    cc, sim, auc = metrics.CC_batch(p, g), metrics.SIM_batch(p, g), metrics.AUC_Judd_batch(p, g)       # jitter on, as train.py:260
+    res = tuple(float(np.mean(v[~np.isnan(v)])) if np.any(~np.isnan(v)) else float("nan") for v in (cc, sim, auc))
+    print(datetime.datetime.now().isoformat()[:-7], " Step:", step, " Metrics:", *res)
+    return res
 
 
 def main():
@@ -83,7 +122,7 @@ def main():
     os.makedirs(model_dir, exist_ok=True)
     if args.pretrain:
         print(args.pretrain, "Using this model to retrain...")
-        sess.load(dict(np.load(args.pretrain)))
+        sess.restore(args.pretrain)                                                 # train.py:204-210
     print("Start training")
     step = 0
     for xs, ys in batches(args, np.random.default_rng(0)):
@@ -93,8 +132,10 @@ def main():
             image = sess.forward(xs, dropout=0.0, training=False)                   # train.py:225-226
             print("Datetime", datetime.datetime.now().isoformat()[:-7], "Training step:", step,
                   float(np.sum(image[0, -1]) * 255.0), float(np.sum(ys[0][-1]) * 255.0), "Training Loss", loss)
+        if step % args.validiter == 0:
+            validate(sess, args, step)                                              # train.py:243-264
         if step % args.saveiter == 0:
-            np.savez(os.path.join(model_dir, "p3d_%d.npz" % step), **sess.save())  # train.py:266-267
+            sess.save_checkpoint(model_dir, step, keep=10)                          # train.py:180-185,266-267
     print("Training Finished!")
     sess.close()
 

@@ -14,6 +14,7 @@
  */
 #ifndef P3D_HIP_H
 #define P3D_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -192,6 +193,10 @@ int p3d_metric_auc_borji(int device, const float* sal, const float* fix, const i
  * H x W -> / 255, float32 [n][H][W][3] (one clip of the NDHWC input); and the grey density maps [n][H0][W0] -> [n][H][W]. */
 int p3d_mapf_frames(int device, const unsigned char* bgr, int n, int H0, int W0, const float mean_rgb[3], int H, int W, float* out);
 int p3d_mapf_density(int device, const unsigned char* grey, int n, int H0, int W0, int H, int W, float* out);
+
+/* CRC-32C of a host buffer (host-side helper of the TensorFlow checkpoint reader / writer, sap3d_tensorflow_amd/tf_checkpoint.py:
+ * the bundle format of train.py:180-185,266-267 checksums every tensor); crc = running value, 0 to start. */
+uint32_t p3d_crc32c(const void* data, size_t n, uint32_t crc);
 
 /* Releases every process-wide device resource of the library (scratch pools, the zero page) and synchronises the
  * device; live handles must be destroyed first.  The Python shim calls it from an atexit hook so that nothing of the

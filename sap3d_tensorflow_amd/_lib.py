@@ -75,6 +75,7 @@ SIGNATURES = {
     "p3d_metric_auc_borji": (C.c_int, [C.c_int, _fp, _fp, _ip, C.c_int, C.c_int, C.c_int, C.c_double, _dp]),
     "p3d_mapf_frames": (C.c_int, [C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp]),
     "p3d_mapf_density": (C.c_int, [C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "p3d_crc32c": (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "p3d_shutdown": (C.c_int, []),
 }
 

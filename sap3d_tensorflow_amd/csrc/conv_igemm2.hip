@@ -37,6 +37,19 @@ constexpr int BK = 32;
 #endif
 template <int BM, int BN>
 struct Ring { static constexpr int stages = (BM >= 128) ? 2 : P3D_RING64; };   // 64x64: deep ring, few steps per K-slice
+// Loader waves (-DP3D_LW64=1; OFF: measured, no gain).  A 64x64 step costs 0.78 us; with the DMA issue compiled out it
+// costs 0.545 us, with the MFMAs compiled out 0.42 us (tools/micro/conv_chain.hip, -DP3D_TUNE_NO_DMA / _NO_MFMA), which
+// suggested that DMA issue (~150 cycles per global_load_lds in the issuing wave) and MFMA issue serialise in one wave's
+// instruction stream.  The 8-wave form below -- waves 0-3 only read fragments and issue MFMAs, waves 4-7 only wait for
+// and issue the LDS-DMA, one of each per SIMD, loaders leaving after the last step -- removes that serialisation, and
+// the step still costs 0.77 us (stage-3 shapes: 57.0 vs 58.4 us per launch at 72 steps; grouped filter gradients 43.9
+// vs 38.3 us, slower).  Deeper rings (4, 5 stages) change nothing either.  What is left is the matrix pipe itself on
+// real (non-zero) operands at the clock the chip holds under load: the DMA-free figure above ran on stale LDS contents.
+#ifndef P3D_LW64
+#define P3D_LW64 0
+#endif
+template <int BM, int BN>
+struct Loaders { static constexpr bool on = (BM == 64 && BN == 64 && P3D_LW64); static constexpr int threads = on ? 512 : 256; };
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
     // LDS destination = wave-uniform base + lane * 16 B
@@ -241,11 +254,24 @@ template <int BM, int BN, bool WT, bool F16>
 __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict__ a_dst, float* __restrict__ b_dst,
                                           const float* __restrict__ a_src, const float* __restrict__ b_src,
                                           f32x16 (&acc)[BM / 64][BN / 64], LoadState<BM / 32, BN / 32>& st, int nsteps,
-                                          int kchunks, int wave, int lane, int wm, int wn) {
+                                          int kchunks, int wave, int lane, int wm, int wn, bool loads, bool computes) {
     constexpr int LPS = BM / 32 + BN / 32;
+    constexpr bool LW = Loaders<BM, BN>::on;
     // loads of this step have landed for this wave; with a 3-stage ring the next step's may still fly
-    wait_vmcnt<(Ring<BM, BN>::stages - 2) * LPS>();
+    if (!LW || loads) wait_vmcnt<(Ring<BM, BN>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();      // ... and for every wave; everyone is also done reading the stage refilled next
+    if constexpr (LW) {
+        if (loads) {
+            issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
+        } else {
+            Frags<BM, BN, WT> f;
+            load_frags<BM, BN, WT>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_frags<BM, BN, WT, F16, 0, BK / 8>(f, acc);
+        }
+        (void)computes;
+        return;
+    }
     Frags<BM, BN, WT> f;
     load_frags<BM, BN, WT>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
     __builtin_amdgcn_sched_barrier(0);      // keep every read above the MFMAs (hipcc otherwise sinks half of them back)
@@ -279,21 +305,21 @@ template <int BM, int BN, bool WT, bool F16, int K>
 struct StepLoop {
     static __device__ __forceinline__ void run(const IgemmArgs& p, float* As, float* Bs, f32x16 (&acc)[BM / 64][BN / 64],
                                                LoadState<BM / 32, BN / 32>& st, int base, int nsteps, int kchunks, int wave,
-                                               int lane, int wm, int wn) {
+                                               int lane, int wm, int wn, bool loads, bool computes) {
         constexpr int STAGES = Ring<BM, BN>::stages;
         if constexpr (K < STAGES) {
             if (base + K < nsteps) {
                 constexpr int D = (K + STAGES - 1) % STAGES;      // stage refilled while stage K is consumed
                 pipe_step<BM, BN, WT, F16>(p, As + D * (BM * BK), Bs + D * (BK * BN), As + K * (BM * BK), Bs + K * (BK * BN), acc, st,
-                                      nsteps, kchunks, wave, lane, wm, wn);
+                                      nsteps, kchunks, wave, lane, wm, wn, loads, computes);
             }
-            StepLoop<BM, BN, WT, F16, K + 1>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn);
+            StepLoop<BM, BN, WT, F16, K + 1>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn, loads, computes);
         }
     }
 };
 
 template <int BM, int BN, bool WT, bool F16 = false>
-__global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(const IgemmArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int LA = BM / 32;                 // A glds per wave per step
     constexpr int A_STAGE = BM * BK;            // floats
@@ -307,7 +333,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool LW = Loaders<BM, BN>::on;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;                              // piece / sub-tile index of this wave in its role
+    const bool loads = !LW || wave8 >= 4, computes = !LW || wave8 < 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
@@ -325,7 +354,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     const int n0 = nt * BN;
 
     const unsigned Mu = (unsigned)M, m0u = (unsigned)m0;      // launcher guarantees M < 2^31
-    for (int r = tid; r < BM; r += 256) {
+    for (int r = tid; r < BM; r += Loaders<BM, BN>::threads) {
         const unsigned m = m0u + r;
         long long ro = -1;
         if (m < Mu) {
@@ -355,12 +384,12 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     LoadState<LA, BN / 32> st;
-    loader_init<BM, BN, WT>(p, st, m0u, Mu, n0, wave, lane, s_begin, kchunks);
+    if (loads) loader_init<BM, BN, WT>(p, st, m0u, Mu, n0, wave, lane, s_begin, kchunks);
     // prologue: STAGES-1 steps in flight; then step k computes from stage k % STAGES while refilling the stage
     // that was consumed one step earlier.  All stage addresses are compile-time constants (StepLoop).
-    PrologueLoop<BM, BN, WT, 0>::run(p, As, Bs, st, nsteps, kchunks, wave, lane);
+    if (loads) PrologueLoop<BM, BN, WT, 0>::run(p, As, Bs, st, nsteps, kchunks, wave, lane);
     for (int base = 0; base < nsteps; base += STAGES)
-        StepLoop<BM, BN, WT, F16, 0>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn);
+        StepLoop<BM, BN, WT, F16, 0>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn, loads, computes);
 
     // ---- epilogue ----------------------------------------------------------------------------------
     // Stage the tile through LDS (the ring is free once the tail DMA has landed) so that global traffic is row-wise
@@ -373,6 +402,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     int* flag = reinterpret_cast<int*>(sred + 4 * BN * 2);      // "this block reduces the slices" (same LDS array: no second object)
     wait_vmcnt<0>();
     __syncthreads();                                            // also orders rowOut (written above) before its readers
+    if (LW && !computes) return;                                // loader waves are done: the epilogue is the compute waves'
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -524,12 +554,12 @@ hipError_t launch_t(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) 
         attr_done = true;
     }
     if (a.f16) {
-        if (a.wT) hipLaunchKernelGGL((igemm2_kernel<BM, BN, true, true>), grid, dim3(256), sm, s, a);
-        else      hipLaunchKernelGGL((igemm2_kernel<BM, BN, false, true>), grid, dim3(256), sm, s, a);
+        if (a.wT) hipLaunchKernelGGL((igemm2_kernel<BM, BN, true, true>), grid, dim3(Loaders<BM, BN>::threads), sm, s, a);
+        else      hipLaunchKernelGGL((igemm2_kernel<BM, BN, false, true>), grid, dim3(Loaders<BM, BN>::threads), sm, s, a);
         return hipGetLastError();
     }
-    if (a.wT) hipLaunchKernelGGL((igemm2_kernel<BM, BN, true>), grid, dim3(256), sm, s, a);
-    else      hipLaunchKernelGGL((igemm2_kernel<BM, BN, false>), grid, dim3(256), sm, s, a);
+    if (a.wT) hipLaunchKernelGGL((igemm2_kernel<BM, BN, true>), grid, dim3(Loaders<BM, BN>::threads), sm, s, a);
+    else      hipLaunchKernelGGL((igemm2_kernel<BM, BN, false>), grid, dim3(Loaders<BM, BN>::threads), sm, s, a);
     return hipGetLastError();
 }
 

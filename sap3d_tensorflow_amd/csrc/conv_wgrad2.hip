@@ -27,6 +27,13 @@ namespace {
 constexpr int BKM = 32;
 template <int BM>
 struct WRing { static constexpr int stages = (BM >= 128) ? 2 : 3; };   // 128x128: 64 KB -> two blocks per CU
+// Loader waves for the 64x64 tile (conv_igemm2.hip, "Loader waves"): waves 0-3 read fragments and issue MFMAs, waves 4-7
+// wait for and issue the LDS-DMA, one of each per SIMD; the loaders leave after the last step.
+#ifndef P3D_LW64
+#define P3D_LW64 0
+#endif
+template <int BM>
+struct WLoaders { static constexpr bool on = (BM == 64 && P3D_LW64); static constexpr int threads = on ? 512 : 256; };
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -172,10 +179,23 @@ __device__ __forceinline__ void pipe_step(const WProb& p, const float* zeros, in
                                           float* __restrict__ b_dst, const float* __restrict__ a_src,
                                           const float* __restrict__ b_src, f32x16 (&acc)[BM / 64][BN / 64], float& bsum,
                                           bool do_bias, WState<BM / 32, BN / 32>& st, unsigned me, int wave, int lane, int wm,
-                                          int wn) {
+                                          int wn, bool loads) {
     constexpr int LPS = BM / 32 + BN / 32;
-    wait_vmcnt<(WRing<BM>::stages - 2) * LPS>();
+    constexpr bool LW = WLoaders<BM>::on;
+    if (!LW || loads) wait_vmcnt<(WRing<BM>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();
+    if constexpr (LW) {
+        if (loads) {
+            issue_stage<BM, BN>(p, zeros, tdd, tdh, tdw, a_dst, b_dst, st, me, wave, lane);
+        } else {
+            WFrags<BM, BN> f;
+            load_wfrags<BM, BN>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_wfrags<BM, BN, 0, BKM>(f, acc);
+            bias_rows<BN>(b_src, bsum, do_bias);
+        }
+        return;
+    }
     WFrags<BM, BN> f;
     load_wfrags<BM, BN>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
     __builtin_amdgcn_sched_barrier(0);      // keep every read above the MFMAs (hipcc otherwise sinks them back, pair by pair)
@@ -193,7 +213,7 @@ constexpr size_t wsmem_bytes() {
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
+__global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const WGroup g) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_STAGE = BKM * BM, B_STAGE = BKM * BN;
     constexpr int STAGES = WRing<BM>::stages;
@@ -203,7 +223,10 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool LW = WLoaders<BM>::on;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;
+    const bool loads = !LW || wave8 >= 4, computes = !LW || wave8 < 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
@@ -253,25 +276,27 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
     float bsum = 0.f;
 
     WState<BM / 32, BN / 32> st;
-    wloader_init<BM, BN>(p, st, (unsigned)ms, k0, n0, wave, lane);
+    if (loads) wloader_init<BM, BN>(p, st, (unsigned)ms, k0, n0, wave, lane);
     const unsigned meu = (unsigned)me;
     if (STAGES == 3) {
         float* A0 = As; float* A1 = As + A_STAGE; float* A2 = As + 2 * A_STAGE;
         float* B0 = Bs; float* B1 = Bs + B_STAGE; float* B2 = Bs + 2 * B_STAGE;
-        issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, st, meu, wave, lane);
-        issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, st, meu, wave, lane);
+        if (loads) {
+            issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, st, meu, wave, lane);
+            issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, st, meu, wave, lane);
+        }
         for (int base = 0; base < nsteps; base += 3) {
-            pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A2, B2, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
-            if (base + 1 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
-            if (base + 2 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, A2, B2, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A2, B2, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn, loads);
+            if (base + 1 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn, loads);
+            if (base + 2 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, A2, B2, acc, bsum, do_bias, st, meu, wave, lane, wm, wn, loads);
         }
     } else {
         float* A0 = As; float* A1 = As + A_STAGE;
         float* B0 = Bs; float* B1 = Bs + B_STAGE;
-        issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, st, meu, wave, lane);
+        if (loads) issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, st, meu, wave, lane);
         for (int base = 0; base < nsteps; base += 2) {
-            pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
-            if (base + 1 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn, loads);
+            if (base + 1 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn, loads);
         }
     }
 
@@ -282,6 +307,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
     int* flag = reinterpret_cast<int*>(bias_lds + BN);
     wait_vmcnt<0>();
     __syncthreads();
+    if (LW && !computes) return;                                 // loader waves are done
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -437,7 +463,7 @@ hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slot
         const hipError_t e = p3d_stream_scratch(s, (size_t)slabs * (BM * BN + BN), (size_t)slots, &g.slab, &g.cnt);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((wgrad2_kernel<BM, BN>), dim3((unsigned)blocks), dim3(256), sm, s, g);
+    hipLaunchKernelGGL((wgrad2_kernel<BM, BN>), dim3((unsigned)blocks), dim3(WLoaders<BM>::threads), sm, s, g);
     return hipGetLastError();
 }
 

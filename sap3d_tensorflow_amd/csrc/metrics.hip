@@ -98,7 +98,7 @@ __global__ __launch_bounds__(TPB) void sim_kernel(const float* a, const float* b
     double acc = 0;
     for (int i = threadIdx.x; i < n; i += TPB) {
         const double x = ((double)pa[i] - mna) / ra / sa, y = ((double)pb[i] - mnb) / rb / sb;
-        acc += (x < y || y != y) ? (y != y ? y : x) : y;       // np.minimum propagates NaN
+        acc += (x != x) ? x : ((y != y) ? y : fmin(x, y));      // np.minimum propagates NaN from either side
     }
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) out[blockIdx.x] = acc;

@@ -1860,14 +1860,17 @@ struct p3d_handle {
             if (c.prof) c.prof->cur_op = ops[i].name;
             ops[i].bwd(c);
             debug_sync("bwd", ops[i], c);
-            if (allreduce && (comm || bucket_hook)) {
-                // gradients at flat offsets >= lo belong to ops i.. only, so they are final now
+            {
+                // gradients at flat offsets >= lo belong to ops i.. only, so they are final now.  The walk (and the flush
+                // of queued filter gradients at every bucket boundary) runs with or without a communicator, so that the
+                // grouping of filter gradients -- hence every bit of the result -- does not depend on the world size or on
+                // whether the call is a train step or the parity hook p3d_backward.
                 while (own_pos > 0 && own_sufmin[own_pos - 1] >= i) --own_pos;
                 const int64_t lo = own_pos < own_sorted.size() ? own_sorted[own_pos].first : n_train;
                 if ((hi > lo && hi - lo >= bucket_floats) || i == 0) {
                     const int64_t start = (i == 0) ? 0 : lo;
                     flush_wgrads(c);                 // the bucket's queued filter gradients must be on the side stream first
-                    if (hi > start) reduce_range(start, hi, c, i);
+                    if (hi > start && allreduce && (comm || bucket_hook)) reduce_range(start, hi, c, i);
                     hi = start;
                 }
             }
@@ -1879,7 +1882,7 @@ struct p3d_handle {
         }
         if (allreduce && (comm || bucket_hook)) {
             if (hi > 0) reduce_range(0, hi, c, 0);
-            if (comm) {
+            if (comm && !bucket_hook) {
                 HIPCHECK(hipEventRecord(ev_comm_done, comm_stream));
                 HIPCHECK(hipStreamWaitEvent(c.s, ev_comm_done, 0));
             }
@@ -1908,12 +1911,14 @@ struct p3d_handle {
         launch(c, "adam_kernel", 0, 28.0 * n_train, [&]() { return p3d_adam(flat_p, flat_g, flat_m, flat_v, n_train, lr_t, c.lr_dev, b1, b2, eps, c.s); });
     }
 
-    // ---- captured train step ------------------------------------------------------------------------
-    // One train step is ~1100 dependent launches on three streams; enqueueing them costs the host 6-11 ms, more
-    // than the GPU needs once the kernels are tuned.  The launch list is static, so it is captured ONCE into a
-    // hipGraph (per dropout rate / pointwise mode / communicator) and replayed; the two per-step scalars (dropout
-    // seed, Adam's bias-corrected step size) live in device memory and are written by a one-thread kernel ahead
-    // of each replay.  P3D_NO_GRAPH=1 keeps the eager launch list (debugging, per-launch profiling).
+    // ---- captured train step (opt-in: P3D_GRAPH=1) ---------------------------------------------------
+    // One train step is ~1000 dependent launches on three streams.  The launch list is static, so it CAN be captured
+    // once into a hipGraph (per dropout rate / pointwise mode / communicator) and replayed; the two per-step scalars
+    // (dropout seed, Adam's bias-corrected step size) then live in device memory and are written by a one-thread
+    // kernel ahead of each replay.  Measured on MI355X / ROCm 7.2 (profiles/r02_graph_vs_eager.json): a replay costs the
+    // host 17.1 ms per step against 9.2 ms of eager enqueueing, and the step takes 20.3 ms instead of 18.2 -- this
+    // runtime walks a graph node by node and pays more per kernel node than per eager launch, so replay is slower
+    // here.  The capture path is kept (and tested) for runtimes where that changes; eager is the default.
     hipGraph_t step_graph = nullptr;
     hipGraphExec_t step_exec = nullptr;
     float graph_drop = -1.f; bool graph_f16 = false; ncclComm_t graph_comm = nullptr; float graph_b1 = 0, graph_b2 = 0, graph_eps = 0;
@@ -1924,8 +1929,8 @@ struct p3d_handle {
         if (step_graph) { hipGraphDestroy(step_graph); step_graph = nullptr; }
     }
     bool graphs_enabled() {
-        static const bool off = getenv("P3D_NO_GRAPH") != nullptr || getenv("P3D_DEBUG_SYNC") != nullptr;
-        return !off && !graph_disabled;
+        static const bool on = getenv("P3D_GRAPH") != nullptr && atoi(getenv("P3D_GRAPH")) != 0 && getenv("P3D_DEBUG_SYNC") == nullptr;
+        return on && !graph_disabled;
     }
     void capture_step_graph(float drop) {
         drop_step_graph();
@@ -2061,6 +2066,10 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         HIPCHECK(hipSetDevice(cfg->device));
         h = new p3d_handle();
         h->cfg = *cfg;
+        if (const char* e = getenv("P3D_BUCKET_MB")) {           // gradient bucket size (also fixes where filter gradients are flushed)
+            const long mb = atol(e);
+            if (mb >= 1) h->bucket_floats = (int64_t)mb * (1 << 18);
+        }
         ensure_zero_page();
         HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
@@ -2685,6 +2694,36 @@ int p3d_mapf_density(int device, const unsigned char* grey, int n, int H0, int W
     HIPCHECK(p3d_mapf_density(src.p, n, H0, W0, dst.p, H, W, nullptr));
     dst.get(out, (size_t)n * H * W);
     API_END
+}
+
+// CRC-32C (Castagnoli) of a host buffer, slicing-by-8: the checksum of TensorFlow's checkpoint bundles
+// (tensorflow/core/lib/hash/crc32c.h), used by the Python reader / writer of sap3d_tensorflow_amd/tf_checkpoint.py on the
+// 248 MB of variables (train.py:180-185, 204-210, 266-267).  `crc` = running value (0 to start).
+uint32_t p3d_crc32c(const void* data, size_t n, uint32_t crc) {
+    static uint32_t T[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+        ready = true;
+    }
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t c = crc ^ 0xFFFFFFFFu;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^
+            T[3][hi & 0xFF] ^ T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) c = T[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
 }
 
 int p3d_shutdown(void) {

@@ -95,6 +95,33 @@ class P3DSession:
         for n in names:
             self.set_param(n, params[n])
 
+    def restore(self, path):
+        """saver.restore (train.py:204-210, gen_pred.py:57-64): `path` is a TF-1.x checkpoint prefix (`.../p3d_1000.ckpt`),
+        a directory holding a `checkpoint` state file (the newest bundle is taken), or an .npz keyed by variable names.
+        Variables the checkpoint lacks raise; extra ones (e.g. Adam slots of another trainer) are ignored."""
+        import os
+        from . import tf_checkpoint as tfc
+        if os.path.isdir(path):
+            latest = tfc.latest_checkpoint(path)
+            if latest is None:
+                raise FileNotFoundError("no `checkpoint` state file in %s" % path)
+            path = latest
+        if path.endswith(".npz"):
+            self.load(dict(np.load(path)))
+        else:
+            self.load(tfc.read_checkpoint(path, names=set(n for n, _, _ in self.variables())))
+        return path
+
+    def save_checkpoint(self, directory, step, keep=10):
+        """saver.save(sess, '<dir>/p3d_<step>.ckpt') with max_to_keep (train.py:180-185,266-267): writes a TF V2 bundle and
+        updates the directory's `checkpoint` state file.  Returns the prefix."""
+        import os
+        from . import tf_checkpoint as tfc
+        prefix = os.path.join(directory, "p3d_%d.ckpt" % step)
+        tfc.write_checkpoint(prefix, self.save())
+        tfc.update_checkpoint_state(directory, prefix, keep)
+        return prefix
+
     def save(self):
         """saver.save: {tf variable name: array} of trainables + moving statistics (train.py:180-185)."""
         return dict((n, self.get_param(n)) for n, _, _ in self.variables())

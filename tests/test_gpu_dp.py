@@ -47,10 +47,13 @@ def test_buckets_tile_the_gradient_buffer_and_are_final(structure, cfg, shape, b
     assert all(hi - lo >= bucket_floats for lo, hi, _ in buckets[:-1])
     ops = [op for _, _, op in buckets]
     assert ops == sorted(ops, reverse=True)
-    # the audit's gradients are the ordinary ones
-    g_audit = s.get_grad(s.variables()[0][0])
+    # the audit's gradients are the ordinary ones (another bucket size regroups the filter-gradient launches, which may
+    # change the last bit of a K-cut sum: compare to fp32 rounding, not bitwise)
+    names = [n for n, _, tr in s.variables() if tr]
+    g_audit = {n: s.get_grad(n) for n in names[:8]}
     s.backward(p3d.synthetic_clip(0, shape + (3,)), p3d.synthetic_target(3, shape), 0.5, seed=3)
-    assert np.array_equal(g_audit, s.get_grad(s.variables()[0][0]))
+    for n, g in g_audit.items():
+        assert np.allclose(g, s.get_grad(n), rtol=1e-4, atol=1e-6 * max(np.abs(g).max(), 1e-30)), n
     s.close()
 
 
@@ -63,11 +66,13 @@ def test_single_rank_allreduce_is_identity(structure):
     x = p3d.synthetic_clip(0, shape + (3,))
     y = p3d.synthetic_target(3, shape)
 
+    os.environ["P3D_BUCKET_MB"] = "1"              # many small buckets; read at create (the bucket walk also fixes where the
+                                                   # queued filter gradients are flushed, so both runs must share it)
+
     def run(with_comm):
         s = P3DSession(structure, batch=shape[0], frames=shape[1], height=shape[2], width=shape[3], base=cfg.base,
                        blocks=cfg.blocks, seed=2)
         if with_comm:
-            os.environ["P3D_BUCKET_MB"] = "1"          # many small buckets
             s.comm_init(P3DSession.comm_unique_id())
         losses = [np.float32(s.train_step(x, y, dropout=0.0)) for _ in range(3)]
         w = {n: s.get_param(n) for n, _, _ in s.variables()}

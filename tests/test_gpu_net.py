@@ -653,6 +653,8 @@ def test_gen_pred_driver_on_gpu(tmp_path):
     from sap3d_tensorflow_amd import P3DSession
     video = np.random.default_rng(0).integers(0, 256, (20, 120, 160, 3)).astype(np.uint8)
     frames = gp.preprocess(video)                                  # [20,112,112,3]
+    from oracle import dataflow as odf
+    assert np.abs(frames[3] - odf.mapf_frame(video[3][..., ::-1], 112, 112)).max() <= 1e-6      # gen_pred.py:117-121 law
     kw = dict(base=16, blocks=(1, 1, 2))
     sb = P3DSession("unet", batch=3, seed=4, **kw)
     out = gp.predict_video(sb, frames, batch=3)

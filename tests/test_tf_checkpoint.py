@@ -1,0 +1,124 @@
+"""the TF-1.x checkpoint bundle the reference's Saver writes (train.py:180-185,204-210,
+266-267).  No TensorFlow-written file exists here (parity unpinned, see sap3d_tensorflow_amd/tf_checkpoint.py); what IS
+pinned: CRC-32C known answers, the published constants of the table format, the protobuf wire layout of a hand-assembled
+entry, round trips, and failure on corrupted files."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from sap3d_tensorflow_amd import tf_checkpoint as tfc
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 appendix B.4 test vectors for CRC-32C
+    assert tfc.crc32c(b"123456789") == 0xE3069283
+    assert tfc.crc32c(bytes(32)) == 0x8A9136AA
+    assert tfc.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert tfc.crc32c(bytes(range(32))) == 0x46DD794E
+    # running value and masking (leveldb: rotate right 15, add 0xa282ead8)
+    assert tfc.crc32c(b"6789", tfc.crc32c(b"12345")) == 0xE3069283
+    assert tfc.mask_crc(0xE3069283) == (((0xE3069283 >> 15) | (0xE3069283 << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+    assert tfc.unmask_crc(tfc.mask_crc(0x12345678)) == 0x12345678
+    big = np.random.default_rng(0).integers(0, 256, 300_000, dtype=np.uint8).tobytes()      # takes the native path when built
+    c = 0
+    for i in range(0, len(big), 4096):
+        c = tfc.crc32c(big[i:i + 4096], c)
+    assert tfc.crc32c(big) == c
+
+
+def test_wire_layout_of_an_entry():
+    # BundleEntryProto{dtype: DT_FLOAT, shape {dim{size:3} dim{size:5}}, offset: 300, size: 60, crc32c: 0x01020304}
+    got = tfc._entry_proto(1, (3, 5), 0, 300, 60, 0x01020304)
+    want = bytes([0x08, 0x01, 0x12, 0x08, 0x12, 0x02, 0x08, 0x03, 0x12, 0x02, 0x08, 0x05, 0x20, 0xAC, 0x02, 0x28, 0x3C, 0x35,
+                  0x04, 0x03, 0x02, 0x01])
+    assert got == want
+    assert tfc._header_proto(1) == bytes([0x08, 0x01, 0x1A, 0x02, 0x08, 0x01])
+
+
+def _model(rng):
+    return {
+        "firstconv1": rng.standard_normal((1, 7, 7, 3, 64)).astype(np.float32),
+        "batch_normalization/gamma": rng.standard_normal(64).astype(np.float32),
+        "batch_normalization/moving_variance": rng.random(64).astype(np.float32),
+        "conv3_0_1": rng.standard_normal((1, 1, 1, 64, 64)).astype(np.float32),
+        "conv3d_transpose_2/bias": np.float32(0.25).reshape(()),          # rank 0
+        "global_step": np.int64(1234).reshape(()),
+        **{"block%d/w" % i: rng.standard_normal((3, i + 1)).astype(np.float32) for i in range(300)},      # several index blocks
+    }
+
+
+def test_round_trip_and_state_file(tmp_path):
+    rng = np.random.default_rng(1)
+    m = _model(rng)
+    prefix = str(tmp_path / "model" / "run" / "p3d_1000.ckpt")
+    tfc.write_checkpoint(prefix, m)
+    assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")
+    raw = open(prefix + ".index", "rb").read()
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57
+    assert os.path.getsize(prefix + ".data-00000-of-00001") == sum(v.nbytes for v in m.values())
+    back = tfc.read_checkpoint(prefix)
+    assert sorted(back) == sorted(m)
+    for k, v in m.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v), k
+    listed = tfc.list_variables(prefix)
+    assert [n for n, _, _ in listed] == sorted(m)
+    assert dict((n, s) for n, s, _ in listed)["firstconv1"] == (1, 7, 7, 3, 64)
+    only = tfc.read_checkpoint(prefix, names={"conv3_0_1"})
+    assert list(only) == ["conv3_0_1"]
+    # Saver bookkeeping: newest first, max_to_keep
+    d = os.path.dirname(prefix)
+    for step in (1000, 2000, 3000):
+        p = os.path.join(d, "p3d_%d.ckpt" % step)
+        tfc.write_checkpoint(p, {"v": np.float32([step])})
+        tfc.update_checkpoint_state(d, p, keep=2)
+    assert tfc.latest_checkpoint(d) == os.path.join(d, "p3d_3000.ckpt")
+    assert tfc.all_checkpoints(d) == ["p3d_2000.ckpt", "p3d_3000.ckpt"]
+    assert not os.path.exists(os.path.join(d, "p3d_1000.ckpt.index"))
+    assert tfc.latest_checkpoint(str(tmp_path)) is None
+
+
+def test_corruption_is_detected(tmp_path):
+    prefix = str(tmp_path / "c.ckpt")
+    tfc.write_checkpoint(prefix, {"a": np.arange(100, dtype=np.float32), "b": np.ones((4, 4), np.float32)})
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    raw[17] ^= 0x40
+    open(data, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        tfc.read_checkpoint(prefix)
+    assert tfc.read_checkpoint(prefix, verify=False)["b"].shape == (4, 4)
+    idx = bytearray(open(prefix + ".index", "rb").read())
+    idx[3] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(ValueError):
+        tfc.read_checkpoint(prefix)
+    open(prefix + ".index", "wb").write(b"not a table")
+    with pytest.raises(ValueError):
+        tfc.read_checkpoint(prefix)
+
+
+@pytest.mark.gpu
+def test_session_restores_a_bundle(tmp_path):
+    """P3DSession.save_checkpoint / restore: a bundle holding every variable of the graph under its TF name round-trips
+    through the HIP session, from a directory (checkpoint state file) and from a prefix."""
+    from oracle import p3d
+    from sap3d_tensorflow_amd import P3DSession
+    cfg = p3d.NetConfig(base=16, blocks=(1, 1, 2))
+    shape = (2, 16, 32, 32)
+    a = P3DSession("unet", batch=2, frames=16, height=32, width=32, base=cfg.base, blocks=cfg.blocks, seed=3)
+    d = str(tmp_path / "model" / "run")
+    prefix = a.save_checkpoint(d, 7)
+    names = [n for n, _, _ in a.variables()]
+    assert [n for n, _, _ in tfc.list_variables(prefix)] == sorted(names)
+    x = p3d.synthetic_clip(0, shape + (3,))
+    want = a.forward(x, 0.0, False)
+    b = P3DSession("unet", batch=2, frames=16, height=32, width=32, base=cfg.base, blocks=cfg.blocks, seed=99)
+    assert not np.array_equal(b.forward(x, 0.0, False), want)
+    assert b.restore(d) == prefix
+    assert np.array_equal(b.forward(x, 0.0, False), want)
+    c = P3DSession("concat", batch=2, frames=16, height=32, width=32, base=cfg.base, blocks=cfg.blocks, seed=1)
+    with pytest.raises(KeyError):
+        c.restore(prefix)            # another head: variables missing from the bundle
+    a.close(); b.close(); c.close()
