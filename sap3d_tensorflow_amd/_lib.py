@@ -103,6 +103,8 @@ def _one_rocm_runtime_per_process():
     import sys
     if "torch" in sys.modules:
         return
+    if mapped_rocm_runtimes():
+        return          # a runtime is already mapped (e.g. rocprofv3 preloads /opt/rocm's): bind to that one
     d = _torch_lib_dir()
     if d is None:
         return

@@ -447,6 +447,23 @@ __global__ __launch_bounds__(256) void fill_uniform_kernel(float* p, long long n
         p[i] = lo + (hi - lo) * u01(seed, (unsigned long long)i);
 }
 
+// tf.truncated_normal(stddev): N(0, stddev) re-drawn until it falls within two standard deviations (what
+// tf.contrib.layers.variance_scaling_initializer(uniform=False) draws from; utils/network.py:212-213,264).  Counter-based:
+// draw k of element i uses the uniform pair (2 (i + k n), 2 (i + k n) + 1).
+__global__ __launch_bounds__(256) void fill_trunc_normal_kernel(float* p, long long n, float stddev, unsigned long long seed) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float z = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            const unsigned long long e = 2ull * (unsigned long long)(i + (long long)k * n);
+            const float u1 = fmaxf(u01(seed, e), 1e-12f), u2 = u01(seed, e + 1);
+            z = sqrtf(-2.f * logf(u1)) * cosf(6.2831853071795865f * u2);
+            if (fabsf(z) <= 2.f) break;
+            z = 0.f;                                 // (32 rejections in a row: probability 1e-43)
+        }
+        p[i] = stddev * z;
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_kernel(const float* dy, int ld, long long M, int C, float* out, float* part,
                                                      unsigned* counters) {
     // thread = one channel; blocks stride over rows; per-block partials, folded in block order by the last arriver of
@@ -693,6 +710,11 @@ hipError_t p3d_copy_strided(float* dst, int lddst, const float* src, int ldsrc, 
 
 hipError_t p3d_fill_uniform(float* p, long n, float lo, float hi, unsigned long long seed, hipStream_t s) {
     hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, (long long)n, lo, hi, seed);
+    return hipGetLastError();
+}
+
+hipError_t p3d_fill_trunc_normal(float* p, long n, float stddev, unsigned long long seed, hipStream_t s) {
+    hipLaunchKernelGGL(fill_trunc_normal_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, (long long)n, stddev, seed);
     return hipGetLastError();
 }
 

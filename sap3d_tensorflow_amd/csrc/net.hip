@@ -2180,13 +2180,13 @@ int p3d_init_params(p3d_handle* h, uint64_t seed) {
             const float L = (float)std::sqrt(6.0 / (fi + fo));
             HIPCHECK(p3d_fill_uniform(p->p, p->count, -L, L, seed * 0x9E3779B97F4A7C15ull + idx, h->stream));
         } else if (p->init == INIT_VS) {
-            // tf.contrib.layers.variance_scaling_initializer(): stddev sqrt(1.3*2/fan_in) (truncated normal in TF;
-            // drawn here as a uniform of the same variance -- parity never depends on the RNG stream, Appendix A.7)
+            // tf.contrib.layers.variance_scaling_initializer() defaults (utils/network.py:212-213,264): factor 2.0,
+            // mode FAN_IN, uniform False -> truncated normal with stddev sqrt(1.3 * 2 / fan_in) (the 1.3 is TF's
+            // correction for the variance the truncation at two standard deviations removes)
             double rf = 1;
             for (size_t i = 0; i + 2 < p->shape.size(); ++i) rf *= (double)p->shape[i];
             const double fan_in = rf * p->shape[p->shape.size() - 2];
-            const float L = (float)(std::sqrt(1.3 * 2.0 / fan_in) * std::sqrt(3.0));
-            HIPCHECK(p3d_fill_uniform(p->p, p->count, -L, L, seed * 0x9E3779B97F4A7C15ull + idx, h->stream));
+            HIPCHECK(p3d_fill_trunc_normal(p->p, p->count, (float)std::sqrt(1.3 * 2.0 / fan_in), seed * 0x9E3779B97F4A7C15ull + idx, h->stream));
         } else {
             const float v = p->init == INIT_ONES ? 1.f : 0.f;
             HIPCHECK(p3d_fill_uniform(p->p, p->count, v, v, 0, h->stream));

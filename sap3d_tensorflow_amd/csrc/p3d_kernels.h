@@ -339,6 +339,7 @@ hipError_t p3d_mapf_density(const unsigned char* grey, int n_frames, int H0, int
 hipError_t p3d_add_inplace(float* dst, int lddst, const float* src, int ldsrc, long M, int C, hipStream_t s);
 hipError_t p3d_copy_strided(float* dst, int lddst, const float* src, int ldsrc, long M, int C, hipStream_t s);
 hipError_t p3d_fill_uniform(float* p, long n, float lo, float hi, unsigned long long seed, hipStream_t s);
+hipError_t p3d_fill_trunc_normal(float* p, long n, float stddev, unsigned long long seed, hipStream_t s);   // N(0, stddev) within 2 stddev
 hipError_t p3d_colsum(const float* dy, int ld, long M, int C, float* out, hipStream_t s);   // out += column sums
 // stem re-layout (elementwise.hip): 3-channel input -> 4-channel rows with the W padding written out; packed weights
 hipError_t p3d_stem_pad(const float* x, float* x4, long long rows, int W, int Wp, int pad, hipStream_t s);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -52,8 +53,32 @@ __global__ __launch_bounds__(256) void read_kernel(const float4* __restrict__ sr
     if (a.x + a.y + a.z + a.w == 123.456f) out[0] = a.x;
 }
 
+__global__ void empty_kernel(float* p) { if (p == (float*)1) p[0] = 0.f; }
+struct Big { char b[336]; };
+__global__ void empty_big_kernel(Big a, float* p) { if (p == (float*)1) p[0] = a.b[0]; }
+
 int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    {   // host cost of one eager launch on this box (the train step enqueues ~970 of them)
+        hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        float* d; CK(hipMalloc(&d, 16));
+        Big big; for (char& c : big.b) c = 1;
+        for (int variant = 0; variant < 2; ++variant)
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipStreamSynchronize(st));
+                timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+                for (int i = 0; i < 2000; ++i) {
+                    if (variant) hipLaunchKernelGGL(empty_big_kernel, dim3(208), dim3(256), 0, st, big, d);
+                    else hipLaunchKernelGGL(empty_kernel, dim3(208), dim3(256), 0, st, d);
+                }
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                CK(hipStreamSynchronize(st));
+                timespec t2; clock_gettime(CLOCK_MONOTONIC, &t2);
+                auto us = [](timespec a, timespec b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
+                if (rep == 2) printf("eager launch of an empty kernel (%s kernel arguments): host %.2f us per launch, %.2f us per launch until the stream drains\n",
+                                     variant ? "336-byte" : "8-byte", us(t0, t1) / 2000, us(t0, t2) / 2000);
+            }
+    }
     float* out; CK(hipMalloc(&out, 16));
     for (int wps = 1; wps <= 2; ++wps) {           // waves per SIMD: 256 CUs x 4 SIMDs x wps waves
         const int blocks = 256 * wps, iters = 20000;
