@@ -203,6 +203,12 @@ def main():
     plane.barrier()
     dt = plane.max_over_ranks(time.perf_counter() - t0)
     loss = sess.last_loss()
+    # host cost of enqueueing ONE step into empty queues (no back-pressure from a full hardware queue, unlike t_enqueued)
+    t1 = time.perf_counter()
+    sess.train_step_device(0.5, seed=999_999)
+    t_one = time.perf_counter() - t1
+    sess.synchronize()
+    plane.barrier()
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
@@ -239,6 +245,7 @@ def main():
             "model_tflops": round(value * FLOP_PER_CLIP_FWD_BWD * (T / 16.0) * (S / 112.0) ** 2 / 1e12, 2) if args.structure == "unet" else None,
             "final_loss": loss,
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
+            "host_enqueue_ms_one_step_empty_queue": round(1e3 * t_one, 3),
             "roofline": roofline_of(rows),
             "kernels": [dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["ms"], 3), avg_us=round(r["avg_us"], 2),
                              tflops=round(r["tflops"], 2), gbs=round(r["gbs"], 1)) for r in rows[:12]],
