@@ -210,7 +210,11 @@ bool p3d_bn_small_ok(long M, int C) { return M <= 1024 && (C % CB) == 0; }
 // wide tensors get 16-channel slabs (64-byte row segments), narrow ones 8-channel slabs (more blocks)
 static hipError_t dispatch(const BnSmallArgs& a, bool bwd, hipStream_t s) {
     if (!p3d_bn_small_ok(a.M, a.C)) return hipErrorInvalidValue;
-    const bool wide = getenv("P3D_BN_CB16") ? atoi(getenv("P3D_BN_CB16")) != 0 : (a.C >= 512 && a.C % 16 == 0 && a.mode != 3 && a.mode != 2);
+    static const int forced = getenv("P3D_BN_CB") ? atoi(getenv("P3D_BN_CB")) : 0;       // tuning: 4, 8 or 16 channels per block
+    if (forced == 4) return launch_small<4>(a, bwd, s);
+    if (forced == 8) return launch_small<8>(a, bwd, s);
+    if (forced == 16 && a.C % 16 == 0) return launch_small<16>(a, bwd, s);
+    const bool wide = a.C >= 512 && a.C % 16 == 0 && a.mode != 3 && a.mode != 2;
     return wide ? launch_small<16>(a, bwd, s) : launch_small<8>(a, bwd, s);
 }
 hipError_t p3d_bn_small_fwd(const BnSmallArgs& a, hipStream_t s) { return dispatch(a, false, s); }

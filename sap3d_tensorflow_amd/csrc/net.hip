@@ -181,10 +181,21 @@ struct StatSink { float* part = nullptr; int cap = 0; int* nparts = nullptr; };
 // or the residue classes of an input gradient / transposed conv).  Small problems slice K across blocks;
 // the slices are folded in a fixed order by the last arriving block (conv_igemm2.hip), so the output needs no
 // zero fill and the statistics epilogue and accumulate mode work either way.
+// fork / join non-null: the launches are independent (residue classes of a transposed conv write disjoint output
+// positions) and each of them leaves CUs idle (196 blocks of 128x128 on 256 CUs): odd ones go to the side stream so that
+// two classes run at a time.
 void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld, int64_t rows, int C, bool accumulate,
-                     const StatSink* stats) {
+                     const StatSink* stats, hipEvent_t fork = nullptr, hipEvent_t join = nullptr) {
     (void)out; (void)ld; (void)rows; (void)C;
     int base = 0;
+    const bool spread = fork && join && c.side && !c.dry && !c.prof && v.size() >= 4;
+    Ctx sc = c;
+    if (spread) {
+        sc.s = c.side;
+        HIPCHECK(hipEventRecord(fork, c.s));
+        HIPCHECK(hipStreamWaitEvent(c.side, fork, 0));
+    }
+    int index = 0;
     for (auto& a : v) {
         a.accum = accumulate ? 1 : 0;
         a.statpart = nullptr; a.stat_base = 0;
@@ -196,7 +207,12 @@ void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld
             a.statpart = stats->part; a.stat_base = base;
             base += mt;
         }
-        launch_igemm(c, a, 1);
+        launch_igemm((spread && (index & 1)) ? sc : c, a, 1);
+        ++index;
+    }
+    if (spread) {
+        HIPCHECK(hipEventRecord(join, c.side));
+        HIPCHECK(hipStreamWaitEvent(c.s, join, 0));
     }
     if (stats && stats->nparts) *stats->nparts = base;
 }
@@ -773,12 +789,13 @@ struct p3d_handle {
         op.bflops = 2 * op.flops; op.bbytes = 2 * op.bytes;
         op.owns = {kern}; if (bias) op.owns.push_back(bias);
         hipEvent_t fork_ev = new_fork_event();
+        hipEvent_t class_fork = new_fork_event(), class_join = new_fork_event();
         op.fwd = [=](const Ctx& c) {
             auto v = igemm_conv_input_side(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, kern->p, bias ? bias->p : nullptr,
                                            0, true);
             BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
             StatSink sink; if (sbn) sink = bn_sink(sbn);
-            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? &sink : nullptr);
+            run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? &sink : nullptr, class_fork, class_join);
         };
         op.bwd = [=](const Ctx& c) {
             // dK[tap][co][ci] = sum dy_big[o][co] * x[i][ci]  (conv wgrad with the roles of x and dy swapped)

@@ -1,6 +1,6 @@
 """Diagnostic: forward error of the HIP path vs the fp64 oracle, next to the fp32 oracle's own error, per tap."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from oracle import p3d, p3d_gn

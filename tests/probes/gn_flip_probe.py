@@ -1,7 +1,7 @@
 """Diagnostic: how often, and where, do GN/CBAM gradients of the HIP path deviate from the fp64 oracle?
 A CBAM arg-max flip in block k perturbs every gradient upstream of k and nothing downstream."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from oracle import p3d, p3d_gn

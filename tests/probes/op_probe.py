@@ -1,6 +1,6 @@
 """Diagnostic: op-level conv parity at in-network extents (larger M than tests/test_gpu_ops.py uses)."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import nn

@@ -1,7 +1,7 @@
 """Diagnostic: does a backward pass depend on what the previous step left in device memory?
 Alternates two inputs A/B; any read-before-write of scratch shows up as an error right after a switch."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from oracle import p3d, p3d_gn

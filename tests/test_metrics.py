@@ -118,6 +118,15 @@ def test_auc_judd_matches_oracle():
     big = rng.random((1080, 960)).astype(np.float32)
     bf = (rng.random((1080, 960)) < 0.002).astype(np.float32)
     assert gm.AUC_Judd(big, bf, jitter=False) == pytest.approx(om.AUC_Judd(big, bf), abs=1e-12)
+    # every pixel fixated: the false-positive rate divides by zero in the reference too (NaN), no crash
+    allfix = np.ones((16, 16), np.float32)
+    small = rng.random((16, 16)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        assert np.isnan(om.AUC_Judd(small, allfix))
+    assert np.isnan(gm.AUC_Judd(small, allfix, jitter=False))
+    # a 1 x N map and a single-row batch
+    line = rng.random((1, 300)).astype(np.float32); lf = (rng.random((1, 300)) < 0.1).astype(np.float32)
+    assert gm.AUC_Judd(line, lf, jitter=False) == pytest.approx(om.AUC_Judd(line, lf), abs=1e-12)
     # two runs are bit-identical (integer counters, fixed-order sums)
     assert gm.AUC_Judd(big, bf, jitter=False) == gm.AUC_Judd(big, bf, jitter=False)
 
