@@ -174,6 +174,9 @@ int p3d_op_conv3d_transpose(int device, const float* x, const int64_t xshape[5],
 int p3d_op_max_pool3d(int device, const float* x, const int64_t xshape[5], const int ksize[3], const int s[3], float* y);
 int p3d_op_max_pool3d_grad(int device, const float* x, const int64_t xshape[5], const int ksize[3], const int s[3],
                            const float* dy, float* dx);
+/* BiasAddGrad of tf.nn.bias_add (the bias of tf.layers.conv3d / conv3d_transpose, p3d.py:147-150): dbias[c] = sum over
+ * rows of dy[row][c]; fixed summation order, bit-identical run to run. */
+int p3d_op_bias_add_grad(int device, const float* dy, int64_t rows, int channels, float* dbias);
 
 /* ---- validation metrics and frame pre-processing: the steps either side of the path.
  *      Host arrays in and out, float64 results.  Maps are float32 [n_maps][n_pix] of ONE shape (the reference's

@@ -25,6 +25,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BKM = 32;
+#ifndef P3D_WGRAD64_LDS_KB
+#define P3D_WGRAD64_LDS_KB 82      // one 64x64 block per CU; see launch_group_t
+#endif
 template <int BM>
 struct WRing { static constexpr int stages = (BM >= 128) ? 2 : 3; };   // 128x128: 64 KB -> two blocks per CU
 // Loader waves for the 64x64 tile (conv_igemm2.hip, "Loader waves"): waves 0-3 read fragments and issue MFMAs, waves 4-7
@@ -394,6 +397,16 @@ __global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const W
     if (do_bias && tid < BN && (n0 + tid) < p.Nc) p.dbias[n0 + tid] += bias_lds[tid];
 }
 
+// LDS request of a launch = residency limiter (see launch_group_t): bytes per block, and the blocks per CU that follow.
+size_t lds_request(int tile) {
+    const size_t need = tile == 128 ? wsmem_bytes<128, 128>() : wsmem_bytes<64, 64>();
+    size_t want = tile == 64 ? (size_t)P3D_WGRAD64_LDS_KB * 1024 : need;
+    static const long forced = getenv("P3D_WGRAD_LDS_KB") ? atol(getenv("P3D_WGRAD_LDS_KB")) : 0;
+    if (tile == 64 && forced > 0 && forced <= 160) want = (size_t)forced * 1024;
+    return want < need ? need : want;
+}
+int blocks_per_cu(int tile) { return (int)std::max<size_t>(1, (size_t)160 * 1024 / lds_request(tile)); }
+
 struct WPlan { int tile; long long tiles; int ks; double cost; };
 // Pick the tile and the number of position-range cuts with a small cost model: blocks run in rounds of
 // `slots` (256 CUs x resident blocks per CU), a round lasts (steps per block + fixed overhead) step-times, and a
@@ -406,7 +419,10 @@ WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
         WPlan w;
         w.tile = T; w.ks = 1; w.cost = 1e300;
         w.tiles = (long long)a.ntaps * ((a.K + T - 1) / T) * ((a.Nc + T - 1) / T);
-        const long long slots = 256 * (T == 128 ? 2 : 3);
+        // the model keeps 3 (2) slots per CU whatever the residency limit: with one resident block per CU the launch then
+        // runs in ~3 short rounds, and short blocks are what lets main-stream blocks in (17.47 vs 17.78 ms / step)
+        static const int per_cu = getenv("P3D_WGRAD_SLOTS") ? atoi(getenv("P3D_WGRAD_SLOTS")) : 0;
+        const long long slots = 256 * (per_cu > 0 ? per_cu : (T == 128 ? 2 : 3));
         const double step_time = T == 128 ? 3.2 : 1.0, overhead = 8.0;
         const long long kmax = std::max<long long>(1, std::min<long long>(steps / 4, 64));
         for (long long ks = 1; ks <= kmax; ks = ks < 16 ? ks + 1 : ks + ks / 8) {
@@ -451,19 +467,25 @@ void fill_prob(WProb& p, const WgradArgs& a) {
 }
 
 template <int BM, int BN>
-hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slots, hipStream_t s) {
-    constexpr size_t sm = wsmem_bytes<BM, BN>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)wgrad2_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        attr_done = true;
-    }
+hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slots, bool greedy, hipStream_t s) {
+    // LDS request = residency limiter.  The filter gradients share the chip with the main stream's chain of small launches,
+    // whose blocks (igemm2 64x64: 48.5 KB of LDS) must find room on every CU while a filter-gradient launch is resident:
+    // three 48 KB blocks per CU leave 16 KB, and every main-stream launch then waits for a filter-gradient block to
+    // retire.  82 KB per 64x64 block = one block per CU: 17.97 -> 17.78 ms / step on one box, 17.93 -> 17.47 on another
+    // (55 KB, two per CU: 17.68).  The plan below still cuts for three slots per CU -- short blocks retire often.
+    static const size_t sm = [] {
+        const size_t want = lds_request(BM);
+        hipFuncSetAttribute((const void*)wgrad2_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        return want;
+    }();
     g.slab = nullptr; g.cnt = nullptr;
     if (slabs > 0) {
         const hipError_t e = p3d_stream_scratch(s, (size_t)slabs * (BM * BN + BN), (size_t)slots, &g.slab, &g.cnt);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((wgrad2_kernel<BM, BN>), dim3((unsigned)blocks), dim3(WLoaders<BM>::threads), sm, s, g);
+    // greedy: nothing else runs beside this launch (the stem's, last of the backward pass) -- full residency
+    const size_t lds = greedy ? wsmem_bytes<BM, BN>() : sm;
+    hipLaunchKernelGGL((wgrad2_kernel<BM, BN>), dim3((unsigned)blocks), dim3(WLoaders<BM>::threads), lds, s, g);
     return hipGetLastError();
 }
 
@@ -509,7 +531,9 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
     g.kstride = kstride;       // slab of (slot, cut) = slot * kstride + cut: disjoint whatever each problem's cut count
     if (blocks >= (1ll << 31)) return hipErrorInvalidValue;
     const long long slabs = kstride > 1 ? (long long)tile0 * kstride : 0;
-    return tile == 128 ? launch_group_t<128, 128>(g, blocks, slabs, tile0, s) : launch_group_t<64, 64>(g, blocks, slabs, tile0, s);
+    const bool greedy = live.size() == 1 && live[0]->greedy;
+    return tile == 128 ? launch_group_t<128, 128>(g, blocks, slabs, tile0, greedy, s)
+                       : launch_group_t<64, 64>(g, blocks, slabs, tile0, greedy, s);
 }
 
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s) { return p3d_launch_wgrad2_group(&a, 1, s); }

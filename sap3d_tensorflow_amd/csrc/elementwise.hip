@@ -481,6 +481,60 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* dy, int ld, lo
     out[c] += t;
 }
 
+// Column sums of a [M x C] tensor, C % 4 == 0, C <= 1024: a thread owns one float4 column group of one row slot
+// (256 / (C/4) rows per pass, eight independent loads in flight), the block folds its row slots through LDS in slot order,
+// and the last arriving block folds the per-block partials in block order -- bit-identical run to run, no atomics.
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ dy, int ld, long long M, int C, float* out,
+                                                      float* part, unsigned* counters) {
+    __shared__ float4 red[256];
+    __shared__ int last_flag;
+    const int L = C >> 2, R = 256 / L;
+    const int lane = threadIdx.x % L, rs = threadIdx.x / L;
+    const bool live = rs < R;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        const long long stride = (long long)gridDim.x * R;
+        long long row = (long long)blockIdx.x * R + rs;
+        const float* base = dy + lane * 4;
+        for (; row + 7 * stride < M; row += 8 * stride) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (row + u * stride) * ld);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; row < M; row += stride) {
+            const float4 v = *reinterpret_cast<const float4*>(base + row * ld);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < L) {
+        float4 t = red[threadIdx.x];
+        for (int r = 1; r < R; ++r) { const float4 v = red[r * L + threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * C + threadIdx.x * 4) = t;
+    }
+    if (!p3d_last_block(counters, gridDim.x, &last_flag)) return;
+    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live)
+        for (unsigned b = rs; b < gridDim.x; b += R) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)b * C + lane * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    __syncthreads();
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < L) {
+        float4 t = red[threadIdx.x];
+        for (int r = 1; r < R; ++r) { const float4 v = red[r * L + threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        float4* o = reinterpret_cast<float4*>(out + threadIdx.x * 4);
+        float4 cur = *o;
+        cur.x += t.x; cur.y += t.y; cur.z += t.z; cur.w += t.w;
+        *o = cur;
+    }
+}
+
 inline unsigned grid_for(long long total, int per_block = 256, int cap = 4096) {
     long long b = (total + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -719,6 +773,18 @@ hipError_t p3d_fill_trunc_normal(float* p, long n, float stddev, unsigned long l
 }
 
 hipError_t p3d_colsum(const float* dy, int ld, long M, int C, float* out, hipStream_t s) {
+    if ((C & 3) == 0 && C >= 4 && C <= 1024 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const int R = 256 / (C >> 2);
+        long long b = (M + (long long)R * 8 - 1) / ((long long)R * 8);      // >= 8 rows per thread before another block pays
+        if (b > 1024) b = 1024;
+        if (b < 1) b = 1;
+        float* slab = nullptr; unsigned* cnt = nullptr;
+        const hipError_t e = p3d_stream_scratch(s, (size_t)b * C, 1, &slab, &cnt);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)b), dim3(256), 0, s, dy, ld, (long long)M, C, out, slab, cnt);
+        return hipGetLastError();
+    }
     long long bx = (M + 63) / 64;
     if (bx > 512) bx = 512;
     if (bx < 1) bx = 1;

@@ -166,6 +166,84 @@ __global__ __launch_bounds__(256) void head_bwd_filter_kernel(HeadArgs a) {
     }
 }
 
+// The same gradient for C % 4 == 0: a thread owns four channels of one position slot (one 16-byte load of x per 27
+// gathered logit gradients and 108 FMAs), and the per-block partials are folded in two levels -- the last arriver of
+// every FOLD consecutive blocks folds that group in block order, the last of those folds the groups in group order --
+// so the serial tail reads FOLD + blocks/FOLD partials instead of `blocks`.
+constexpr int HEAD_FOLD = 32;
+__global__ __launch_bounds__(256) void head_bwd_filter4_kernel(HeadArgs a) {
+    __shared__ float4 red[256];
+    __shared__ int last_flag;
+    const int C = a.C, L = C >> 2, R = 256 / L;
+    const int lane = threadIdx.x % L, rs = threadIdx.x / L;
+    const bool live = rs < R;
+    const long long total = (long long)a.N * a.D * a.H * a.W;
+    const int Do = 2 * a.D, Ho = 2 * a.H, Wo = 2 * a.W;
+    float4 acc[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bsum = 0.f;
+    if (live) {
+        for (long long g = (long long)blockIdx.x * R + rs; g < total; g += (long long)gridDim.x * R) {
+            long long t = g;
+            const int w = (int)(t % a.W); t /= a.W;
+            const int h = (int)(t % a.H); t /= a.H;
+            const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + g * C + lane * 4);
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const int od = 2 * d + kd, oh = 2 * h + kh, ow = 2 * w + kk;
+                        float gdl = 0.f;
+                        if (od < Do && oh < Ho && ow < Wo) gdl = a.dlogits[(((long long)n * Do + od) * Ho + oh) * Wo + ow];
+                        float4& s = acc[(kd * 3 + kh) * 3 + kk];
+                        s.x = fmaf(gdl, xv.x, s.x); s.y = fmaf(gdl, xv.y, s.y); s.z = fmaf(gdl, xv.z, s.z); s.w = fmaf(gdl, xv.w, s.w);
+                        if (lane == 0 && kd < 2 && kh < 2 && kk < 2) bsum += gdl;   // each output counted once
+                    }
+        }
+    }
+    float* mine = a.part + (size_t)blockIdx.x * 28 * C;
+#pragma unroll
+    for (int q = 0; q < 27; ++q) {
+        red[threadIdx.x] = live ? acc[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        if (threadIdx.x < L) {
+            float4 s = red[threadIdx.x];
+            for (int r = 1; r < R; ++r) { const float4 v = red[r * L + threadIdx.x]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+            *reinterpret_cast<float4*>(mine + q * C + threadIdx.x * 4) = s;
+        }
+        __syncthreads();
+    }
+    red[threadIdx.x].x = (live && lane == 0) ? bsum : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += red[r * L].x;
+        mine[27 * C] = s;
+    }
+    const int nvals = 27 * C + 1;
+    const unsigned ngroups = (gridDim.x + HEAD_FOLD - 1) / HEAD_FOLD, group = blockIdx.x / HEAD_FOLD;
+    const unsigned first = group * HEAD_FOLD, in_group = min((unsigned)HEAD_FOLD, gridDim.x - first);
+    float* gpart = a.part + (size_t)gridDim.x * 28 * C;
+    if (!p3d_last_block(a.counter + 1 + group, in_group, &last_flag)) return;
+    for (int i = threadIdx.x; i < nvals; i += blockDim.x) {
+        float t = 0.f;
+#pragma unroll 8
+        for (unsigned b = 0; b < in_group; ++b) t += a.part[(size_t)(first + b) * 28 * C + i];
+        gpart[(size_t)group * 28 * C + i] = t;
+    }
+    if (!p3d_last_block(a.counter, ngroups, &last_flag)) return;
+    for (int i = threadIdx.x; i < nvals; i += blockDim.x) {
+        float t = 0.f;
+#pragma unroll 8
+        for (unsigned gidx = 0; gidx < ngroups; ++gidx) t += gpart[(size_t)gidx * 28 * C + i];
+        if (i < 27 * C) a.dk[i] += t; else a.dbias[0] += t;
+    }
+}
+
 // ---- tf.layers.conv3d(x, 1, 3, 1, 'same') head of the GN decoder-block network (gn/p3d_gn.py:537): the same
 // Cout = 1 stencil at stride 1, SAME padding 1 on every side.  logits[o] = bias + sum_k <x[o+k-1,:], K[k,:,0]>.
 __global__ __launch_bounds__(256) void headc_fwd_kernel(HeadArgs a) {
@@ -355,6 +433,18 @@ hipError_t p3d_head_bwd_input(const HeadArgs& a, hipStream_t s) {
 hipError_t p3d_head_bwd_filter(const HeadArgs& a, hipStream_t s) {
     if (a.C > 256 || a.C < 1) return hipErrorInvalidValue;
     const long long total = (long long)a.N * a.D * a.H * a.W;
+    if ((a.C & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0) {
+        const int R = 256 / (a.C >> 2);
+        long long b = (total + (long long)R * 4 - 1) / ((long long)R * 4);
+        if (b > 1024) b = 1024;
+        if (b < 1) b = 1;
+        const long long groups = (b + HEAD_FOLD - 1) / HEAD_FOLD;
+        HeadArgs aa = a;
+        const hipError_t e = p3d_stream_scratch(s, (size_t)(b + groups) * 28 * a.C, (int)(1 + groups), &aa.part, &aa.counter);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(head_bwd_filter4_kernel, dim3((unsigned)b), dim3(256), 0, s, aa);
+        return hipGetLastError();
+    }
     const int lanes = 256 / a.C;
     long long b = (total + (long long)lanes * 32 - 1) / ((long long)lanes * 32);
     if (b > 256) b = 256;       // the last arriving block folds b partial gradients: keep that tail short

@@ -127,6 +127,9 @@ struct Ctx {
     std::vector<std::pair<float*, size_t>>* dry = nullptr;
     // buffers inside [z0, z1) are zeroed wholesale at the start of the phase: no per-op memset
     const char* z0 = nullptr; const char* z1 = nullptr;
+    // backward of the decoder: side-stream jobs are parked here and released when the walk reaches the encoder (run_backward)
+    std::vector<std::pair<hipEvent_t, std::function<void(const Ctx&)>>>* defer = nullptr;
+    const char* bwd_op = nullptr;     // name of the op whose backward is running (diagnostics)
 };
 
 template <typename F>
@@ -221,6 +224,20 @@ void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld
 template <typename F>
 void on_side_stream(const Ctx& c, hipEvent_t ev, F&& f) {
     if (c.dry || !c.side || !ev) { f(c); return; }
+    // timing diagnostic (WRONG RESULTS): P3D_TUNE_SKIP_SIDE=deconv,block1 drops the side-stream jobs queued during the backward of
+    // ops whose name contains one of the substrings -- what that share of the filter gradients costs the step
+    static const char* skip = getenv("P3D_TUNE_SKIP_SIDE");
+    if (skip && c.bwd_op) {
+        std::string pats(skip), name(c.bwd_op);
+        size_t a = 0;
+        while (a <= pats.size()) {
+            size_t b = pats.find(',', a);
+            if (b == std::string::npos) b = pats.size();
+            if (b > a && name.find(pats.substr(a, b - a)) != std::string::npos) return;
+            a = b + 1;
+        }
+    }
+    if (c.defer) { c.defer->emplace_back(ev, std::function<void(const Ctx&)>(f)); return; }   // f must own what it names
     HIPCHECK(hipEventRecord(ev, c.s));
     HIPCHECK(hipStreamWaitEvent(c.side, ev, 0));
     Ctx sc = c;
@@ -622,6 +639,7 @@ struct p3d_handle {
     struct PendingWgrad { WgradArgs a; std::string op; double flops, bytes; };
     std::vector<PendingWgrad> wq;
     std::vector<hipEvent_t> wq_events;          // one fork event per flush of a backward pass, reused every step
+    int defer_release_op = -1;                  // backward: side-stream jobs of ops after this one wait until the walk reaches it
     size_t wq_flushes = 0;
     static int64_t wgrad_tiles64(const WgradArgs& a) { return (int64_t)a.ntaps * ((a.K + 63) / 64) * ((a.Nc + 63) / 64); }
     void queue_wgrad(const Ctx& c, const WgradArgs& a0) {
@@ -654,7 +672,7 @@ struct p3d_handle {
         double fl = 0, by = 0;
         for (auto& q : wq) { probs.push_back(q.a); fl += q.flops; by += q.bytes; }
         const char* name = probs.size() == 1 ? p3d_wgrad2_variant(probs[0]) : "wgrad2_kernel<64,64>(grouped)";
-        on_side_stream(c, ev, [&](const Ctx& sc) {
+        on_side_stream(c, ev, [=](const Ctx& sc) {          // by value: the job may be parked (Ctx::defer)
             launch(sc, name, fl, by, [&]() { return p3d_launch_wgrad2_group(probs.data(), (int)probs.size(), sc.s); });
         });
         wq.clear();
@@ -709,7 +727,7 @@ struct p3d_handle {
                 run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? &sink : nullptr);
             };
             op.bwd = [=](const Ctx& c) {
-                on_side_stream(c, fork_ev, [&](const Ctx& sc) {
+                on_side_stream(c, fork_ev, [=](const Ctx& sc) {
                     if (!sc.dry) HIPCHECK(hipMemsetAsync(dw4, 0, (size_t)KH * K4 * Cout * sizeof(float), sc.s));
                     IgemmArgs ga;
                     memset(&ga, 0, sizeof(ga));
@@ -719,6 +737,7 @@ struct p3d_handle {
                     wa.x = x4; wa.N = ga.N; wa.Di = ga.Di; wa.Hi = ga.Hi; wa.Wi = ga.Wi; wa.ldx = 4; wa.K = K4;
                     wa.Gd = ga.Gd; wa.Gh = ga.Gh; wa.Gw = ga.Gw; wa.isd = ga.isd; wa.ish = ga.ish; wa.isw = ga.isw;
                     wa.dy = y->g; wa.ldy = y->ld; wa.Nc = Cout; wa.dw = dw4; wa.ksplit = 1;
+                    wa.greedy = 1;                     // the last launch of the backward pass: the main stream is done
                     wa.ntaps = KH;
                     for (int kh = 0; kh < KH; ++kh) wa.taps[kh] = ga.taps[kh];
                     launch_wgrad(sc, wa);
@@ -801,7 +820,7 @@ struct p3d_handle {
             // dK[tap][co][ci] = sum dy_big[o][co] * x[i][ci]  (conv wgrad with the roles of x and dy swapped)
             queue_wgrad(c, wgrad_conv(g, x->N, y->g, y->ld, Cout, x->p, x->ld, Cin, kern->g, nullptr));
             if (bias)
-                on_side_stream(c, fork_ev, [&](const Ctx& sc) {
+                on_side_stream(c, fork_ev, [=](const Ctx& sc) {
                     launch(sc, "colsum_kernel", 0, 4.0 * y->rows() * Cout, [&]() { return p3d_colsum(y->g, y->ld, y->rows(), Cout, bias->g, sc.s); });
                 });
             if (xflag) {
@@ -1719,7 +1738,7 @@ struct p3d_handle {
         op.bwd = [=](const Ctx& c) {
             if (*xflag) throw P3dError("head input gradient must be the first writer");
             // the filter gradient is a weight gradient like any other: side stream, off the critical path
-            on_side_stream(c, head_fork, [&](const Ctx& sc) {
+            on_side_stream(c, head_fork, [=](const Ctx& sc) {
                 if (transpose) launch(sc, "head_bwd_filter_kernel", hf, hb, [&]() { return p3d_head_bwd_filter(mk(), sc.s); });
                 else launch(sc, "headc_bwd_filter_kernel", hf, hb, [&]() { return p3d_headc_bwd_filter(mk(), sc.s); });
             });
@@ -1749,6 +1768,9 @@ struct p3d_handle {
         for (auto& f : late_bind) f();
         late_bind.clear();
         index_gradient_owners();
+        for (int i = 0; i < (int)ops.size(); ++i)              // last op of the encoder's last bottleneck (ops are named blockN/...)
+            if (ops[i].name.compare(0, 5, "block") == 0) defer_release_op = i;
+        if (defer_release_op == (int)ops.size() - 1) defer_release_op = -1;
         tune_plans();
         plan_zero_arenas();
     }
@@ -1873,8 +1895,26 @@ struct p3d_handle {
         int64_t hi = n_train;                        // grads in [hi, n_train) are already handed to the comm stream
         size_t own_pos = own_sorted.size();
         wq.clear(); wq_flushes = 0;
+        // The decoder's backward saturates the chip (deconv input gradients at 80+ TFLOP/s) while the encoder's is a chain of
+        // small launches that leaves most CUs idle.  The decoder's side-stream jobs (filter and bias gradients) are therefore
+        // parked and released when the walk reaches the encoder, where they fill idle CUs instead of halving the rate of the
+        // main stream's big kernels.  Grouping and summation order do not change, only the launch time.
+        std::vector<std::pair<hipEvent_t, std::function<void(const Ctx&)>>> parked;
+        static const bool no_defer = getenv("P3D_DEFER_SIDE") && atoi(getenv("P3D_DEFER_SIDE")) == 0;
+        const bool defer_on = c.side && !no_defer && defer_release_op > 0;
+        auto release_parked = [&]() {
+            c.defer = nullptr;
+            for (auto& job : parked) on_side_stream(c, job.first, job.second);
+            parked.clear();
+        };
         for (int i = (int)ops.size() - 1; i >= 0; --i) {
             if (c.prof) c.prof->cur_op = ops[i].name;
+            c.bwd_op = ops[i].name.c_str();
+            if (i == 1) flush_wgrads(c);      // what is still queued runs beside the stem's normalisation backward, not after it
+            if (defer_on) {
+                if (i > defer_release_op) c.defer = &parked;
+                else if (c.defer) release_parked();
+            }
             ops[i].bwd(c);
             debug_sync("bwd", ops[i], c);
             {
@@ -1887,15 +1927,34 @@ struct p3d_handle {
                 if ((hi > lo && hi - lo >= bucket_floats) || i == 0) {
                     const int64_t start = (i == 0) ? 0 : lo;
                     flush_wgrads(c);                 // the bucket's queued filter gradients must be on the side stream first
-                    if (hi > start && allreduce && (comm || bucket_hook)) reduce_range(start, hi, c, i);
-                    hi = start;
+                    if (i == 0 && c.defer) release_parked();
+                    // while jobs are parked their gradients are not on the side stream yet: the range stays with the walk
+                    // and is handed over at the first boundary after the release
+                    if (!c.defer) {
+                        if (hi > start && allreduce && (comm || bucket_hook)) reduce_range(start, hi, c, i);
+                        hi = start;
+                    }
                 }
             }
         }
         flush_wgrads(c);
+        if (c.defer) release_parked();
+        static const bool tune_tail = getenv("P3D_TUNE_TAIL") != nullptr;   // diagnostic: how long the side stream outlasts the main one
+        static hipEvent_t tail_main = nullptr, tail_side = nullptr;
+        if (tune_tail && c.side && !c.dry) {
+            if (!tail_main) { HIPCHECK(hipEventCreate(&tail_main)); HIPCHECK(hipEventCreate(&tail_side)); }
+            HIPCHECK(hipEventRecord(tail_main, c.s));
+            HIPCHECK(hipEventRecord(tail_side, c.side));
+        }
         if (c.side) {       // weight gradients must be complete before the optimiser (and the next step)
             HIPCHECK(hipEventRecord(ev_side_done, c.side));
             HIPCHECK(hipStreamWaitEvent(c.s, ev_side_done, 0));
+        }
+        if (tune_tail && c.side && !c.dry) {
+            HIPCHECK(hipEventSynchronize(tail_main)); HIPCHECK(hipEventSynchronize(tail_side));
+            float ms = 0.f;
+            const hipError_t e = hipEventElapsedTime(&ms, tail_main, tail_side);
+            fprintf(stderr, "[p3d tune] side stream ends %.3f ms after the main stream's backward\n", e == hipSuccess ? ms : -1.f);
         }
         if (allreduce && (comm || bucket_hook)) {
             if (hi > 0) reduce_range(0, hi, c, 0);
@@ -2088,9 +2147,15 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
             if (mb >= 1) h->bucket_floats = (int64_t)mb * (1 << 18);
         }
         ensure_zero_page();
-        HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-        HIPCHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        {   // the main stream carries the dependent chain of small launches and the comm stream the all-reduces: both above
+            // the side stream's filter gradients (measured: no effect on the step time on this ROCm, 17.98 vs 17.95 ms;
+            // what does help is keeping the filter gradients' residency low, conv_wgrad2.hip launch_group_t)
+            int least = 0, greatest = 0;
+            HIPCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHECK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, greatest));
+            HIPCHECK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, greatest));
+            HIPCHECK(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least));
+        }
         HIPCHECK(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_side_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
@@ -2603,6 +2668,17 @@ int p3d_op_max_pool3d_grad(int device, const float* x, const int64_t xs[5], cons
     a.x = dx.p; a.dy = dy.p; a.dx = dg.p;
     HIPCHECK(p3d_maxpool_bwd(a, nullptr));
     dg.get(dxh, prod5(xs));
+    API_END
+}
+
+int p3d_op_bias_add_grad(int device, const float* dyh, int64_t rows, int channels, float* dbias) {
+    API_BEGIN
+    if (!dyh || !dbias) throw P3dError("null argument");
+    if (rows < 0 || channels < 1) throw P3dError("bias_add_grad needs rows >= 0 and channels >= 1");
+    HIPCHECK(hipSetDevice(device));
+    DevBuf dy(rows * channels, dyh), db(channels);
+    if (rows > 0) HIPCHECK(p3d_colsum(dy.p, channels, (long)rows, channels, db.p, nullptr));
+    db.get(dbias, channels);
     API_END
 }
 

@@ -76,6 +76,15 @@ def conv3d_transpose(x, kernel, strides, bias=None, device=0):
     return y
 
 
+def bias_add_grad(dy, device=0):
+    """BiasAddGrad (gradient of the bias of tf.layers.conv3d / conv3d_transpose): sum of dy over every axis but the last."""
+    g = _f32(dy)
+    c = g.shape[-1]
+    out = np.empty((c,), np.float32)
+    check(lib().p3d_op_bias_add_grad(device, fptr(g), g.size // c if c else 0, c, fptr(out)))
+    return out
+
+
 def max_pool3d(x, ksize, strides, padding="SAME", device=0):
     """tf.nn.max_pool3d(x, [1,kd,kh,kw,1], [1,sd,sh,sw,1], 'SAME')."""
     x = _f32(x)

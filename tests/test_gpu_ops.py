@@ -113,3 +113,17 @@ def test_max_pool3d(xs, k, s):
     t.ops[-1]()
     got_dx = ops.max_pool3d_grad(x, k, s, dy)
     close(got_dx, X.grad)
+
+
+@pytest.mark.parametrize("rows,c", [(1, 4), (17, 64), (5000, 64), (40000, 128), (3001, 1024), (777, 6), (50, 2048), (0, 8)])
+def test_bias_add_grad(rows, c):
+    """BiasAddGrad of the conv / transposed-conv bias (p3d.py:147-150): column sums, fixed order -> bit-identical runs.
+    Shapes cover the float4 path (C % 4 == 0, C <= 1024), the scalar one (C = 6, 2048), one row, and no rows."""
+    from sap3d_tensorflow_amd import ops
+    rng = np.random.default_rng(rows * 131 + c)
+    dy = rnd(rng, (rows, c))
+    got = ops.bias_add_grad(dy)
+    want = dy.astype(np.float64).sum(0)
+    scale = np.abs(dy.astype(np.float64)).sum(0).max() if rows else 1.0
+    assert np.abs(got - want).max() <= 2e-6 * max(scale, 1.0)
+    assert np.array_equal(got, ops.bias_add_grad(dy))

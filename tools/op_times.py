@@ -1,0 +1,49 @@
+"""Per-launch device times of one train step (p3d_profile_step) for the ops whose name matches a regular expression:
+python tools/op_times.py 'deconv3|stem' [--structure unet] [--batch 8] -> name, kernel, phase, us, GFLOP, TFLOP/s, GB/s."""
+import argparse
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("pattern")
+    ap.add_argument("--structure", default="unet")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=112)
+    a = ap.parse_args()
+    from sap3d_tensorflow_amd import P3DSession, synthetic as law
+    sess = P3DSession(a.structure, batch=a.batch, frames=a.frames, height=a.size, width=a.size, seed=0)
+    sess.set_adam(1e-4)
+    shape = (a.batch, a.frames, a.size, a.size)
+    sess.upload(law.synthetic_clip(0, shape + (3,)), law.synthetic_target(1, shape))
+    for _ in range(3):
+        sess.train_step_device(0.5, 1)
+    sess.synchronize()
+    best = None
+    for rep in range(3):                        # keep each launch's fastest of three profiled steps
+        recs = sess.profile_step(0.5, 2 + rep)
+        if best is None:
+            best = recs
+        else:
+            for b, r in zip(best, recs):
+                b["ms"] = min(b["ms"], r["ms"])
+    rx = re.compile(a.pattern)
+    tot = 0.0
+    for r in best:
+        if rx.search(r["name"]):
+            t = max(r["ms"], 1e-6) * 1e-3
+            tot += r["ms"]
+            print("%-44s %-34s ph%d %9.1f us %8.2f GF %7.1f TF/s %7.0f GB/s" % (r["name"][:44], r["kernel"][:34], r["phase"], r["ms"] * 1e3,
+                  r["flops"] / 1e9, r["flops"] / t / 1e12, r["bytes"] / t / 1e9))
+    print("matched total %.3f ms of %.3f ms" % (tot, sum(r["ms"] for r in best)))
+    sess.close()
+
+
+if __name__ == "__main__":
+    main()
