@@ -1808,6 +1808,12 @@ struct p3d_handle {
                     throw P3dError("gradient bucket order broken at op " + ops[i].name + " / variable " + kv.first->name);
         }
         if (pos != 0) throw P3dError("gradient bucket walk does not reach offset 0");
+        // split point of the two-part optimiser step (run_backward): the lowest offset above which no variable belongs to op 0;
+        // usable when it is 16-byte aligned and op 0 (the stem conv) really owns something below it
+        adam_split = 0;
+        size_t q = own_sorted.size();
+        while (q > 0 && own_sufmin[q - 1] >= 1) --q;
+        if (q > 0 && q < own_sorted.size() && (own_sorted[q].first & 3) == 0) adam_split = own_sorted[q].first;
     }
 
     // One forward + backward over whatever the buffers hold: sizes the per-stream scratch of the K-sliced launches
@@ -1885,8 +1891,12 @@ struct p3d_handle {
         HIPCHECK(hipMemsetAsync(d_loss, 0, sizeof(double), c.s));
         launch(c, "smooth_l1_kernel", 0, 12.0 * pred->rows(), [&]() { return p3d_smooth_l1(pred->p, d_y, pred->rows(), d_loss, d_dlogits, head_sigmoid ? 1 : 0, c.s); });
     }
-    void run_backward(const Ctx& c0, bool allreduce) {
+    // with_adam: the optimiser step is part of the call and split in two -- every variable but the first op's is updated while
+    // that op's filter gradient (the stem's: the last launch of the pass, alone on the side stream) is still running, the
+    // first op's own variables after it.  Returns whether Adam ran (false: the caller launches run_adam).
+    bool run_backward(const Ctx& c0, bool allreduce, bool with_adam = false) {
         Ctx c = c0; c.z0 = zb; c.z1 = zb + zb_bytes;
+        bool adam_done = false;
         static const bool no_side = getenv("P3D_NO_SIDE_STREAM") != nullptr;
         c.side = (c.prof || no_side) ? nullptr : side_stream;      // per-launch profiling keeps one stream
         if (zb_bytes) HIPCHECK(hipMemsetAsync(zb, 0, zb_bytes, c.s));
@@ -1911,6 +1921,29 @@ struct p3d_handle {
             if (c.prof) c.prof->cur_op = ops[i].name;
             c.bwd_op = ops[i].name.c_str();
             if (i == 1) flush_wgrads(c);      // what is still queued runs beside the stem's normalisation backward, not after it
+            if (i == 0 && adam_split > 0 && adam_split < n_train && c.side && !c.dry) {
+                // every gradient at offsets >= adam_split is final once the side stream has drained what is queued so far:
+                // hand that range over now, so that neither its all-reduce nor its Adam waits for the first op's filter gradient
+                flush_wgrads(c);
+                if (c.defer) release_parked();
+                const bool reduce = allreduce && (comm || bucket_hook);
+                if (hi > adam_split) {
+                    if (reduce) reduce_range(adam_split, hi, c, 1);
+                    hi = adam_split;
+                }
+                static const bool no_split = getenv("P3D_SPLIT_ADAM") && atoi(getenv("P3D_SPLIT_ADAM")) == 0;     // A/B runs
+                if (with_adam && !no_split) {
+                    HIPCHECK(hipEventRecord(ev_side_early, c.side));
+                    HIPCHECK(hipStreamWaitEvent(c.s, ev_side_early, 0));
+                    if (reduce && comm && !bucket_hook) {
+                        HIPCHECK(hipEventRecord(ev_comm_early, comm_stream));
+                        HIPCHECK(hipStreamWaitEvent(c.s, ev_comm_early, 0));
+                    }
+                    adam_begin(c);
+                    adam_range(c, adam_split, n_train);
+                    adam_done = true;
+                }
+            }
             if (defer_on) {
                 if (i > defer_release_op) c.defer = &parked;
                 else if (c.defer) release_parked();
@@ -1954,7 +1987,8 @@ struct p3d_handle {
             HIPCHECK(hipEventSynchronize(tail_main)); HIPCHECK(hipEventSynchronize(tail_side));
             float ms = 0.f;
             const hipError_t e = hipEventElapsedTime(&ms, tail_main, tail_side);
-            fprintf(stderr, "[p3d tune] side stream ends %.3f ms after the main stream's backward\n", e == hipSuccess ? ms : -1.f);
+            fprintf(stderr, "[p3d tune] side stream ends %.3f ms after the main stream's backward%s (adam_split %lld)\n", e == hipSuccess ? ms : -1.f,
+                    adam_done ? " + first Adam part" : "", (long long)adam_split);
         }
         if (allreduce && (comm || bucket_hook)) {
             if (hi > 0) reduce_range(0, hi, c, 0);
@@ -1963,6 +1997,8 @@ struct p3d_handle {
                 HIPCHECK(hipStreamWaitEvent(c.s, ev_comm_done, 0));
             }
         }
+        if (adam_done) adam_range(c, 0, adam_split);
+        return adam_done;
     }
     // audit hook (p3d_debug_bucket_audit): called in place of the collective with the range and the op whose backward
     // had just run when the bucket was handed over
@@ -1982,10 +2018,20 @@ struct p3d_handle {
         const double t = (double)t_step;
         return (float)(lr * std::sqrt(1.0 - std::pow((double)b2, t)) / (1.0 - std::pow((double)b1, t)));
     }
-    void run_adam(const Ctx& c) {        // c.lr_dev set: the step size comes from device memory (graph replay), `step` is the caller's
-        const float lr_t = c.lr_dev ? 0.f : adam_lr_t(++step);
-        launch(c, "adam_kernel", 0, 28.0 * n_train, [&]() { return p3d_adam(flat_p, flat_g, flat_m, flat_v, n_train, lr_t, c.lr_dev, b1, b2, eps, c.s); });
+    float cur_lr_t = 0.f;
+    int64_t adam_split = 0;              // flat offset below which only the first op's variables live (0: no split)
+    hipEvent_t ev_side_early = nullptr, ev_comm_early = nullptr;
+    void adam_begin(const Ctx& c) {      // c.lr_dev set: the step size comes from device memory (graph replay), `step` is the caller's
+        cur_lr_t = c.lr_dev ? 0.f : adam_lr_t(++step);
     }
+    void adam_range(const Ctx& c, int64_t lo, int64_t hi) {
+        if (hi <= lo) return;
+        const float lr_t = cur_lr_t;
+        launch(c, "adam_kernel", 0, 28.0 * (hi - lo), [&]() {
+            return p3d_adam(flat_p + lo, flat_g + lo, flat_m + lo, flat_v + lo, hi - lo, lr_t, c.lr_dev, b1, b2, eps, c.s);
+        });
+    }
+    void run_adam(const Ctx& c) { adam_begin(c); adam_range(c, 0, n_train); }
 
     // ---- captured train step (opt-in: P3D_GRAPH=1) ---------------------------------------------------
     // One train step is ~1000 dependent launches on three streams.  The launch list is static, so it CAN be captured
@@ -2015,8 +2061,7 @@ struct p3d_handle {
         try {
             run_forward(c);
             run_loss(c);
-            run_backward(c, true);
-            run_adam(c);
+            if (!run_backward(c, true, true)) run_adam(c);
         } catch (...) {
             hipGraph_t g = nullptr;
             hipStreamEndCapture(stream, &g);
@@ -2031,7 +2076,8 @@ struct p3d_handle {
     void train_step_device(float drop, uint64_t seed) {
         if (!graphs_enabled()) {
             Ctx c; c.training = true; c.drop = drop; c.seed = seed; c.update_moving = true; c.s = stream;
-            run_forward(c); run_loss(c); run_backward(c, true); run_adam(c);
+            run_forward(c); run_loss(c);
+            if (!run_backward(c, true, true)) run_adam(c);
             return;
         }
         if (!step_exec || graph_drop != drop || graph_f16 != pointwise_f16 || graph_comm != comm || graph_b1 != b1 || graph_b2 != b2 ||
@@ -2078,6 +2124,8 @@ struct p3d_handle {
         for (hipEvent_t e : fork_events) hipEventDestroy(e);
         for (hipEvent_t e : wq_events) hipEventDestroy(e);
         if (ev_side_done) hipEventDestroy(ev_side_done);
+        if (ev_side_early) hipEventDestroy(ev_side_early);
+        if (ev_comm_early) hipEventDestroy(ev_comm_early);
         if (ev_side_bucket) hipEventDestroy(ev_side_bucket);
         if (side_stream) hipStreamDestroy(side_stream);
         for (void* p : allocs) hipFree(p);
@@ -2157,6 +2205,8 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
             HIPCHECK(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least));
         }
         HIPCHECK(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&h->ev_side_early, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&h->ev_comm_early, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_side_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_bucket, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&h->ev_comm_done, hipEventDisableTiming));

@@ -43,8 +43,10 @@ def test_buckets_tile_the_gradient_buffer_and_are_final(structure, cfg, shape, b
         assert hi == hi_expected and 0 <= lo < hi, (lo, hi, hi_expected)
         hi_expected = lo
     assert hi_expected == 0
-    # every bucket but the tail collects at least the requested size; ops are walked in reverse
-    assert all(hi - lo >= bucket_floats for lo, hi, _ in buckets[:-1])
+    # every bucket collects at least the requested size, except the two that end the pass: what is final before the first
+    # op's filter gradient is handed over ahead of it (so neither its all-reduce nor its Adam waits for that launch), and
+    # the first op's own variables after it; ops are walked in reverse
+    assert all(hi - lo >= bucket_floats for lo, hi, _ in buckets[:-2])
     ops = [op for _, _, op in buckets]
     assert ops == sorted(ops, reverse=True)
     # the audit's gradients are the ordinary ones (another bucket size regroups the filter-gradient launches, which may
