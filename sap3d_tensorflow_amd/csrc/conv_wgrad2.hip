@@ -25,6 +25,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BKM = 32;
+#ifndef P3D_WGRAD_POLITE_ROWS
+#define P3D_WGRAD_POLITE_ROWS 8192
+#endif
 #ifndef P3D_WGRAD64_LDS_KB
 #define P3D_WGRAD64_LDS_KB 82      // one 64x64 block per CU; see launch_group_t
 #endif
@@ -531,7 +534,16 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
     g.kstride = kstride;       // slab of (slot, cut) = slot * kstride + cut: disjoint whatever each problem's cut count
     if (blocks >= (1ll << 31)) return hipErrorInvalidValue;
     const long long slabs = kstride > 1 ? (long long)tile0 * kstride : 0;
-    const bool greedy = live.size() == 1 && live[0]->greedy;
+    // Residency (launch_group_t): problems over few positions belong to the encoder's later stages, whose main-stream launches
+    // are small and must find LDS on every CU -> one block per CU; problems over many positions run beside chip-filling
+    // launches, where limiting residency only slows the filter gradient (unet++ head: 66.5 vs 60.1 ms / step) -> full.
+    bool polite = false, force = false;
+    long long max_m = 0;
+    for (auto* a : live) {
+        polite |= a->polite != 0; force |= a->greedy != 0;
+        max_m = std::max(max_m, (long long)a->N * a->Gd * a->Gh * a->Gw);
+    }
+    const bool greedy = !polite && (force || max_m > P3D_WGRAD_POLITE_ROWS);
     return tile == 128 ? launch_group_t<128, 128>(g, blocks, slabs, tile0, greedy, s)
                        : launch_group_t<64, 64>(g, blocks, slabs, tile0, greedy, s);
 }

@@ -640,6 +640,7 @@ struct p3d_handle {
     std::vector<PendingWgrad> wq;
     std::vector<hipEvent_t> wq_events;          // one fork event per flush of a backward pass, reused every step
     int defer_release_op = -1;                  // backward: side-stream jobs of ops after this one wait until the walk reaches it
+    double defer_budget = 0, parked_flops = 0;  // ... up to this many filter-gradient FLOPs (what the encoder's idle CUs can absorb)
     size_t wq_flushes = 0;
     static int64_t wgrad_tiles64(const WgradArgs& a) { return (int64_t)a.ntaps * ((a.K + 63) / 64) * ((a.Nc + 63) / 64); }
     void queue_wgrad(const Ctx& c, const WgradArgs& a0) {
@@ -672,6 +673,10 @@ struct p3d_handle {
         double fl = 0, by = 0;
         for (auto& q : wq) { probs.push_back(q.a); fl += q.flops; by += q.bytes; }
         const char* name = probs.size() == 1 ? p3d_wgrad2_variant(probs[0]) : "wgrad2_kernel<64,64>(grouped)";
+        if (c.defer) {            // parked: it will run beside the encoder's chain of small launches -- low residency (conv_wgrad2.hip)
+            for (auto& pr : probs) pr.polite = 1;
+            parked_flops += fl;
+        }
         on_side_stream(c, ev, [=](const Ctx& sc) {          // by value: the job may be parked (Ctx::defer)
             launch(sc, name, fl, by, [&]() { return p3d_launch_wgrad2_group(probs.data(), (int)probs.size(), sc.s); });
         });
@@ -1771,6 +1776,13 @@ struct p3d_handle {
         for (int i = 0; i < (int)ops.size(); ++i)              // last op of the encoder's last bottleneck (ops are named blockN/...)
             if (ops[i].name.compare(0, 5, "block") == 0) defer_release_op = i;
         if (defer_release_op == (int)ops.size() - 1) defer_release_op = -1;
+        // the encoder's last stage leaves CUs idle only while its tensors are small (784 rows at 8 clips of 16x112x112); the
+        // budget is the decoder filter-gradient work of the unet at that size (124 GFLOP), measured to be absorbed
+        defer_budget = 0;
+        if (!blocks.empty()) {
+            const Act* last = blocks.rbegin()->second.out;
+            if (last && last->rows() <= 2048) defer_budget = 130e9;
+        }
         tune_plans();
         plan_zero_arenas();
     }
@@ -1909,9 +1921,13 @@ struct p3d_handle {
         // small launches that leaves most CUs idle.  The decoder's side-stream jobs (filter and bias gradients) are therefore
         // parked and released when the walk reaches the encoder, where they fill idle CUs instead of halving the rate of the
         // main stream's big kernels.  Grouping and summation order do not change, only the launch time.
+        // Parking is bounded by what that phase can absorb (defer_budget, finalize_build): a head that is many times the
+        // encoder (unet++, the GN nets) parks its first jobs only, and nothing is parked when the encoder's own launches fill
+        // the chip (32x224x224 clips).
         std::vector<std::pair<hipEvent_t, std::function<void(const Ctx&)>>> parked;
         static const bool no_defer = getenv("P3D_DEFER_SIDE") && atoi(getenv("P3D_DEFER_SIDE")) == 0;
-        const bool defer_on = c.side && !no_defer && defer_release_op > 0;
+        const bool defer_on = c.side && !no_defer && defer_release_op > 0 && defer_budget > 0;
+        parked_flops = 0;
         auto release_parked = [&]() {
             c.defer = nullptr;
             for (auto& job : parked) on_side_stream(c, job.first, job.second);
@@ -1925,7 +1941,7 @@ struct p3d_handle {
                 // every gradient at offsets >= adam_split is final once the side stream has drained what is queued so far:
                 // hand that range over now, so that neither its all-reduce nor its Adam waits for the first op's filter gradient
                 flush_wgrads(c);
-                if (c.defer) release_parked();
+                if (c.defer || !parked.empty()) release_parked();
                 const bool reduce = allreduce && (comm || bucket_hook);
                 if (hi > adam_split) {
                     if (reduce) reduce_range(adam_split, hi, c, 1);
@@ -1945,8 +1961,8 @@ struct p3d_handle {
                 }
             }
             if (defer_on) {
-                if (i > defer_release_op) c.defer = &parked;
-                else if (c.defer) release_parked();
+                if (i > defer_release_op) c.defer = parked_flops < defer_budget ? &parked : nullptr;
+                else if (c.defer || !parked.empty()) release_parked();
             }
             ops[i].bwd(c);
             debug_sync("bwd", ops[i], c);
@@ -1960,10 +1976,10 @@ struct p3d_handle {
                 if ((hi > lo && hi - lo >= bucket_floats) || i == 0) {
                     const int64_t start = (i == 0) ? 0 : lo;
                     flush_wgrads(c);                 // the bucket's queued filter gradients must be on the side stream first
-                    if (i == 0 && c.defer) release_parked();
+                    if (i == 0 && (c.defer || !parked.empty())) release_parked();
                     // while jobs are parked their gradients are not on the side stream yet: the range stays with the walk
                     // and is handed over at the first boundary after the release
-                    if (!c.defer) {
+                    if (parked.empty()) {
                         if (hi > start && allreduce && (comm || bucket_hook)) reduce_range(start, hi, c, i);
                         hi = start;
                     }
@@ -1971,7 +1987,7 @@ struct p3d_handle {
             }
         }
         flush_wgrads(c);
-        if (c.defer) release_parked();
+        if (c.defer || !parked.empty()) release_parked();
         static const bool tune_tail = getenv("P3D_TUNE_TAIL") != nullptr;   // diagnostic: how long the side stream outlasts the main one
         static hipEvent_t tail_main = nullptr, tail_side = nullptr;
         if (tune_tail && c.side && !c.dry) {

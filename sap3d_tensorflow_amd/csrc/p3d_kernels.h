@@ -92,6 +92,7 @@ struct WgradArgs {
     float* dbias;         // [Nc] or null (column sums of dy, added by tap 0 / k-tile 0 blocks)
     int ksplit;           // (chosen by the launcher)
     int greedy;           // 1: launched when nothing else is running -- take every LDS slot (conv_wgrad2.hip, launch_group_t)
+    int polite;           // 1: runs beside a chain of small launches whatever its own size -- one block per CU
     int stem_wfloats, stem_wstep, stem_wpad;
     const float* zeros;   // zero page (wgrad2 only)
     int ntaps;
