@@ -16,6 +16,7 @@
 // atomics anywhere: two runs give bit-identical gradients.
 #include "p3d_kernels.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -400,34 +401,44 @@ __global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const W
     if (do_bias && tid < BN && (n0 + tid) < p.Nc) p.dbias[n0 + tid] += bias_lds[tid];
 }
 
-// LDS request of a launch = residency limiter (see launch_group_t): bytes per block, and the blocks per CU that follow.
-size_t lds_request(int tile) {
-    const size_t need = tile == 128 ? wsmem_bytes<128, 128>() : wsmem_bytes<64, 64>();
-    size_t want = tile == 64 ? (size_t)P3D_WGRAD64_LDS_KB * 1024 : need;
+// LDS request of a launch = residency limiter (see launch_group_t): bytes per block of a (tm x tn) tile.
+size_t lds_need(int tm, int tn) {
+    if (tm == 128 && tn == 128) return wsmem_bytes<128, 128>();
+    if (tm == 128) return wsmem_bytes<128, 64>();
+    if (tn == 128) return wsmem_bytes<64, 128>();
+    return wsmem_bytes<64, 64>();
+}
+size_t lds_request(int tm, int tn) {
+    const size_t need = lds_need(tm, tn);
+    if (tm != 64 || tn != 64) return need;
+    size_t want = (size_t)P3D_WGRAD64_LDS_KB * 1024;
     static const long forced = getenv("P3D_WGRAD_LDS_KB") ? atol(getenv("P3D_WGRAD_LDS_KB")) : 0;
-    if (tile == 64 && forced > 0 && forced <= 160) want = (size_t)forced * 1024;
+    if (forced > 0 && forced <= 160) want = (size_t)forced * 1024;
     return want < need ? need : want;
 }
-int blocks_per_cu(int tile) { return (int)std::max<size_t>(1, (size_t)160 * 1024 / lds_request(tile)); }
 
-struct WPlan { int tile; long long tiles; int ks; double cost; };
+struct WPlan { int tm, tn; long long tiles; int ks; double cost; };
 // Pick the tile and the number of position-range cuts with a small cost model: blocks run in rounds of
-// `slots` (256 CUs x resident blocks per CU), a round lasts (steps per block + fixed overhead) step-times, and a
-// 128x128 step is ~3.2x a 64x64 step (4x the MFMAs, better LDS-DMA efficiency).  This avoids e.g. 540 blocks on
-// 512 slots (a second round with 28 blocks).  `other_tiles`: 64x64 tiles of the other problems in the same launch.
+// `slots` (256 CUs x resident blocks per CU), a round lasts (steps per block + fixed overhead) step-times; a 128x128 step
+// is ~3.2x a 64x64 step (4x the MFMAs, better LDS-DMA efficiency), a 64x128 / 128x64 step ~1.75x.  This avoids e.g. 540
+// blocks on 512 slots (a second round with 28 blocks).  `other_tiles`: 64x64 tiles of the other problems in the same launch
+// (groups use 64x64 only).
 WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const long long steps = (M + BKM - 1) / BKM;
-    auto best_for = [&](int T) {
+    auto best_for = [&](int TM_, int TN_) {
         WPlan w;
-        w.tile = T; w.ks = 1; w.cost = 1e300;
-        w.tiles = (long long)a.ntaps * ((a.K + T - 1) / T) * ((a.Nc + T - 1) / T);
+        w.tm = TM_; w.tn = TN_; w.ks = 1; w.cost = 1e300;
+        w.tiles = (long long)a.ntaps * ((a.K + TM_ - 1) / TM_) * ((a.Nc + TN_ - 1) / TN_);
         // the model keeps 3 (2) slots per CU whatever the residency limit: with one resident block per CU the launch then
         // runs in ~3 short rounds, and short blocks are what lets main-stream blocks in (17.47 vs 17.78 ms / step)
         static const int per_cu = getenv("P3D_WGRAD_SLOTS") ? atoi(getenv("P3D_WGRAD_SLOTS")) : 0;
-        const long long slots = 256 * (per_cu > 0 ? per_cu : (T == 128 ? 2 : 3));
-        const double step_time = T == 128 ? 3.2 : 1.0, overhead = 8.0;
-        const long long kmax = std::max<long long>(1, std::min<long long>(steps / 4, 64));
+        const int area = TM_ * TN_;
+        const long long slots = 256 * (per_cu > 0 ? per_cu : (area > 4096 ? 2 : 3));
+        const double step_time = area == 16384 ? 3.2 : (area == 8192 ? 1.75 : 1.0), overhead = 8.0;
+        // one tile or two over a long position range (a 1x1x1 conv to 32 channels at 1.6 M positions): many short cuts
+        const long long kcap = w.tiles + other_tiles <= 8 ? 256 : 64;
+        const long long kmax = std::max<long long>(1, std::min<long long>(steps / 4, kcap));
         for (long long ks = 1; ks <= kmax; ks = ks < 16 ? ks + 1 : ks + ks / 8) {
             const long long blocks = (w.tiles + other_tiles) * ks;
             const long long rounds = (blocks + slots - 1) / slots;
@@ -438,12 +449,27 @@ WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
         }
         return w;
     };
-    const WPlan small = best_for(64);
-    if (other_tiles == 0 && a.K >= 128 && a.Nc >= 128) {
-        const WPlan big = best_for(128);
-        if (big.cost <= small.cost) return big;
+    // A launch over many positions (the decoder's deconvs, stage 1) keeps every CU busy for hundreds of steps; there a
+    // 64x128 tile does more per LDS-DMA byte: deconv3's filter gradient at 32x224x224 alone 7.76 -> 6.85 ms (128x128: 6.88),
+    // the step 89.7 -> 87.6 ms (128x128: 87.0, but 17.34 vs 17.22 ms on the 16x112x112 step; 128x64: worse on both).  The
+    // cut count still comes from the model above: a cost model of its own that counted work per CU picked fewer, longer
+    // blocks and lost 0.2-3.6 ms per step on every workload although each filter gradient alone was faster.
+    const bool busy = other_tiles == 0 && M > P3D_WGRAD_POLITE_ROWS && a.Nc >= 128 && getenv("P3D_WGRAD_NO_RECT") == nullptr &&
+                      getenv("P3D_WGRAD_TILE") == nullptr;
+    if (busy) return best_for(64, 128);
+    WPlan best = best_for(64, 64);
+    if (other_tiles == 0) {
+        // tests and sweeps force a tile shape (read per call, unlike the tuning switches): P3D_WGRAD_TILE=64x128 | 128x64 | 128x128 | 64x64
+        if (const char* f = getenv("P3D_WGRAD_TILE")) {
+            int fm = 0, fn = 0;
+            if (sscanf(f, "%dx%d", &fm, &fn) == 2 && (fm == 64 || fm == 128) && (fn == 64 || fn == 128)) {
+                if ((fm == 64 || a.K >= 128) && (fn == 64 || a.Nc >= 128)) return best_for(fm, fn);
+                return best;
+            }
+        }
+        if (a.K >= 128 && a.Nc >= 128) { const WPlan w = best_for(128, 128); if (w.cost <= best.cost) best = w; }
     }
-    return small;
+    return best;
 }
 
 bool wgrad_ok(const WgradArgs& a) {
@@ -470,15 +496,16 @@ void fill_prob(WProb& p, const WgradArgs& a) {
 }
 
 template <int BM, int BN>
-hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slots, bool greedy, hipStream_t s) {
+hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slots, bool greedy, bool polite, hipStream_t s) {
     // LDS request = residency limiter.  The filter gradients share the chip with the main stream's chain of small launches,
     // whose blocks (igemm2 64x64: 48.5 KB of LDS) must find room on every CU while a filter-gradient launch is resident:
     // three 48 KB blocks per CU leave 16 KB, and every main-stream launch then waits for a filter-gradient block to
     // retire.  82 KB per 64x64 block = one block per CU: 17.97 -> 17.78 ms / step on one box, 17.93 -> 17.47 on another
     // (55 KB, two per CU: 17.68).  The plan below still cuts for three slots per CU -- short blocks retire often.
     static const size_t sm = [] {
-        const size_t want = lds_request(BM);
-        hipFuncSetAttribute((const void*)wgrad2_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        const size_t want = lds_request(BM, BN);
+        hipFuncSetAttribute((const void*)wgrad2_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)std::max(want, lds_request(64, 64)));
         return want;
     }();
     g.slab = nullptr; g.cnt = nullptr;
@@ -487,14 +514,21 @@ hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slot
         if (e != hipSuccess) return e;
     }
     // greedy: nothing else runs beside this launch (the stem's, last of the backward pass) -- full residency
-    const size_t lds = greedy ? wsmem_bytes<BM, BN>() : sm;
+    // not greedy: a 64x64 tile takes its polite request (one block per CU); a larger tile at least as much when the launch
+    // is marked polite (it was parked to run beside the encoder's chain)
+    size_t lds = greedy ? wsmem_bytes<BM, BN>() : sm;
+    if (polite && lds < lds_request(64, 64)) lds = lds_request(64, 64);
     hipLaunchKernelGGL((wgrad2_kernel<BM, BN>), dim3((unsigned)blocks), dim3(WLoaders<BM>::threads), lds, s, g);
     return hipGetLastError();
 }
 
 }  // namespace
 
-const char* p3d_wgrad2_variant(const WgradArgs& a) { return plan(a).tile == 128 ? "wgrad2_kernel<128,128>" : "wgrad2_kernel<64,64>"; }
+const char* p3d_wgrad2_variant(const WgradArgs& a) {
+    const WPlan w = plan(a);
+    return w.tm == 128 ? (w.tn == 128 ? "wgrad2_kernel<128,128>" : "wgrad2_kernel<128,64>")
+                       : (w.tn == 128 ? "wgrad2_kernel<64,128>" : "wgrad2_kernel<64,64>");
+}
 
 // One launch for up to P3D_WGRAD_GROUP problems.  A single problem may take the 128x128 tile; groups use 64x64.
 hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s) {
@@ -512,7 +546,8 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
     memset(&g, 0, sizeof(g));
     g.nprob = (int)live.size();
     g.zeros = live[0]->zeros;
-    const int tile = live.size() == 1 ? plan(*live[0]).tile : 64;
+    const WPlan solo = live.size() == 1 ? plan(*live[0]) : WPlan{64, 64, 0, 1, 0.0};
+    const int tm = solo.tm, tn = solo.tn;
     long long tiles64_all = 0;
     for (auto* a : live) tiles64_all += (long long)a->ntaps * ((a->K + 63) / 64) * ((a->Nc + 63) / 64);
     long long blocks = 0;
@@ -523,7 +558,7 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
         fill_prob(p, a);
         const long long my64 = (long long)a.ntaps * ((a.K + 63) / 64) * ((a.Nc + 63) / 64);
         const WPlan w = live.size() == 1 ? plan(a) : plan(a, tiles64_all - my64);
-        const long long tiles = (long long)a.ntaps * ((a.K + tile - 1) / tile) * ((a.Nc + tile - 1) / tile);
+        const long long tiles = (long long)a.ntaps * ((a.K + tm - 1) / tm) * ((a.Nc + tn - 1) / tn);
         p.ksplit = w.ks;
         p.blk0 = (int)blocks;
         p.tile0 = tile0;
@@ -544,8 +579,10 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
         max_m = std::max(max_m, (long long)a->N * a->Gd * a->Gh * a->Gw);
     }
     const bool greedy = !polite && (force || max_m > P3D_WGRAD_POLITE_ROWS);
-    return tile == 128 ? launch_group_t<128, 128>(g, blocks, slabs, tile0, greedy, s)
-                       : launch_group_t<64, 64>(g, blocks, slabs, tile0, greedy, s);
+    if (tm == 128) return tn == 128 ? launch_group_t<128, 128>(g, blocks, slabs, tile0, greedy, polite, s)
+                                    : launch_group_t<128, 64>(g, blocks, slabs, tile0, greedy, polite, s);
+    return tn == 128 ? launch_group_t<64, 128>(g, blocks, slabs, tile0, greedy, polite, s)
+                     : launch_group_t<64, 64>(g, blocks, slabs, tile0, greedy, polite, s);
 }
 
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s) { return p3d_launch_wgrad2_group(&a, 1, s); }

@@ -40,6 +40,9 @@ CONV_CASES = [
     ((1, 4, 12, 12, 32), (3, 3, 3), 8, (1, 1, 1)),       # decoder2_conv1
     ((2, 3, 6, 6, 4), (3, 3, 3), 8, (1, 1, 1)),          # 4 input channels: one 16-byte chunk per row
     ((1, 4, 10, 10, 8), (3, 3, 3), 8, (2, 2, 2)),        # input-gradient shape of decoder2_deconv
+    ((1, 4, 8, 8, 64), (3, 3, 3), 128, (1, 1, 1)),       # filter gradient [64 x 128] per tap: 64x128 tile
+    ((1, 4, 8, 8, 128), (3, 3, 3), 64, (1, 1, 1)),       # [128 x 64]: 128x64 tile
+    ((2, 16, 32, 32, 64), (1, 1, 1), 32, (1, 1, 1)),     # one filter-gradient tile over 32768 positions: up to 256 cuts
 ]
 
 
@@ -127,3 +130,22 @@ def test_bias_add_grad(rows, c):
     scale = np.abs(dy.astype(np.float64)).sum(0).max() if rows else 1.0
     assert np.abs(got - want).max() <= 2e-6 * max(scale, 1.0)
     assert np.array_equal(got, ops.bias_add_grad(dy))
+
+
+@pytest.mark.parametrize("tile", ["64x64", "64x128", "128x64", "128x128"])
+@pytest.mark.parametrize("xs,k,co", [((2, 4, 14, 14, 256), (1, 3, 3), 128), ((1, 4, 8, 8, 128), (3, 3, 3), 192), ((3, 2, 9, 7, 136), (1, 1, 1), 132)])
+def test_filter_gradient_tile_shapes(tile, xs, k, co, monkeypatch):
+    """Every tile shape of the filter-gradient kernel (conv_wgrad2.hip) on the same problems -- ragged K / Nc tails included
+    (136 x 132) -- against the oracle, and bit-identical run to run (fixed cut order)."""
+    from sap3d_tensorflow_amd import ops
+    monkeypatch.setenv("P3D_WGRAD_TILE", tile)
+    rng = np.random.default_rng(5)
+    x = rnd(rng, xs)
+    s = (1, 1, 1)
+    dy = rnd(rng, xs[:4] + (co,))
+    want_dw = nn.conv3d_backward_filter(x.astype(np.float64), dy.astype(np.float64), k + (xs[4], co), s)
+    got_dw, got_db = ops.conv3d_backprop_filter(x, k + (xs[4], co), dy, s, with_bias=True)
+    close(got_dw, want_dw)
+    close(got_db, dy.astype(np.float64).reshape(-1, co).sum(0))
+    again, _ = ops.conv3d_backprop_filter(x, k + (xs[4], co), dy, s, with_bias=True)
+    assert np.array_equal(got_dw, again)
