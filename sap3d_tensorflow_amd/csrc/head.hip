@@ -70,6 +70,68 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
     }
 }
 
+// The same forward with L = C/4 lanes per input position (L a power of two): every lane takes four channels of each of
+// the eight neighbours -- a position's row is one coalesced 16*L-byte read instead of 64 lanes striding C floats apart
+// (which thrashed the L1: 208 GB/s at 32x224x224) -- and the eight partial outputs are summed across the L lanes by
+// xor-shuffles in a fixed order.
+template <int L>
+__global__ __launch_bounds__(256) void head_fwd_lanes_kernel(HeadArgs a) {
+    extern __shared__ float kw[];     // [27][C]
+    const int C = a.C;
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) kw[i] = a.k[i];
+    __syncthreads();
+    const long long total = (long long)a.N * a.D * a.H * a.W;
+    const float bias = a.bias[0];
+    const int part = threadIdx.x % L, c = part * 4;
+    const long long stride = (long long)gridDim.x * (256 / L);
+    for (long long g = (long long)blockIdx.x * (256 / L) + threadIdx.x / L; g < total; g += stride) {
+        long long t = g;
+        const int w = (int)(t % a.W); t /= a.W;
+        const int h = (int)(t % a.H); t /= a.H;
+        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+        float out[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[q] = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 2; ++dw) {
+                    if (d - dd < 0 || h - dh < 0 || w - dw < 0) continue;
+                    const float4 xv = ld4(a.x + ((((long long)n * a.D + (d - dd)) * a.H + (h - dh)) * a.W + (w - dw)) * C + c);
+                    // taps reachable from this neighbour: per axis delta=0 -> (k=0,p=0),(k=1,p=1); delta=1 -> (k=2,p=0)
+#pragma unroll
+                    for (int a0 = 0; a0 < (dd ? 1 : 2); ++a0)
+#pragma unroll
+                        for (int a1 = 0; a1 < (dh ? 1 : 2); ++a1)
+#pragma unroll
+                            for (int a2 = 0; a2 < (dw ? 1 : 2); ++a2) {
+                                const int kd = dd ? 2 : a0, pd = dd ? 0 : a0, kh = dh ? 2 : a1, ph = dh ? 0 : a1, kk = dw ? 2 : a2, pw = dw ? 0 : a2;
+                                const float4 kv = *reinterpret_cast<const float4*>(kw + ((kd * 3 + kh) * 3 + kk) * C + c);
+                                out[(pd * 2 + ph) * 2 + pw] += xv.x * kv.x + xv.y * kv.y + xv.z * kv.z + xv.w * kv.w;
+                            }
+                }
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[q] += __shfl_xor(out[q], o);
+        if (part == 0) {
+            const int Do = 2 * a.D, Ho = 2 * a.H, Wo = 2 * a.W;
+#pragma unroll
+            for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const long long o = (((long long)n * Do + 2 * d + pd) * Ho + 2 * h + ph) * Wo + 2 * w;
+                    const float v0 = out[(pd * 2 + ph) * 2] + bias, v1 = out[(pd * 2 + ph) * 2 + 1] + bias;
+                    *reinterpret_cast<float2*>(a.logits + o) = make_float2(v0, v1);
+                    *reinterpret_cast<float2*>(a.pred + o) =
+                        a.sigmoid ? make_float2(1.f / (1.f + expf(-v0)), 1.f / (1.f + expf(-v1))) : make_float2(v0, v1);
+                }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void head_bwd_input_kernel(HeadArgs a) {
     extern __shared__ float kw[];
     const int C = a.C, c4n = C >> 2;
@@ -415,6 +477,16 @@ hipError_t p3d_headc_bwd_filter(const HeadArgs& a, hipStream_t s) {
 hipError_t p3d_head_fwd(const HeadArgs& a, hipStream_t s) {
     if ((a.C & 3) || a.C > 256) return hipErrorInvalidValue;
     const long long total = (long long)a.N * a.D * a.H * a.W;
+    const int L = a.C >> 2;
+    if (L > 1 && L <= 64 && (L & (L - 1)) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0) {
+        long long b = (total * L + 255) / 256;
+        if (b > 16384) b = 16384;
+        const size_t sm = 27 * a.C * sizeof(float);
+#define P3D_HL(L_) case L_: hipLaunchKernelGGL(head_fwd_lanes_kernel<L_>, dim3((unsigned)b), dim3(256), sm, s, a); break;
+        switch (L) { P3D_HL(2) P3D_HL(4) P3D_HL(8) P3D_HL(16) P3D_HL(32) P3D_HL(64) }
+#undef P3D_HL
+        return hipGetLastError();
+    }
     long long b = (total + 255) / 256;
     if (b > 8192) b = 8192;
     hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)b), dim3(256), 27 * a.C * sizeof(float), s, a);
