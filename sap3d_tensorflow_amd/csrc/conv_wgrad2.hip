@@ -61,6 +61,7 @@ struct WProb {
     int blk0;            // first block of this problem in the launch's 1-D grid
     int tile0;           // first (tile) slot of this problem in the scratch slabs / counters
     int ntaps;
+    int pair;            // K <= 32: a 64-row tile holds TWO taps (rows 0-31 tap 2i, rows 32-63 tap 2i+1) -- the stem's K = 28
     signed char tap[P3D_MAX_TAPS][4];      // dd, dh, dw, weight slab
 };
 struct WGroup {
@@ -98,7 +99,7 @@ __device__ __forceinline__ void wloader_init(const WProb& p, WState<BM / 32, BN 
         st.gw[i] = (int)(m % (unsigned)p.Gw); unsigned t = m / (unsigned)p.Gw;
         st.gh[i] = (int)(t % (unsigned)p.Gh); t /= (unsigned)p.Gh;
         st.gd[i] = (int)(t % (unsigned)p.Gd); st.n[i] = (int)(t / (unsigned)p.Gd);
-        st.kc[i] = k0 + (lane % A_LPR) * 4;
+        st.kc[i] = p.pair ? ((lane % A_LPR) % (A_LPR / 2)) * 4 : k0 + (lane % A_LPR) * 4;
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
@@ -251,10 +252,11 @@ __global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const W
         p.N = src.N; p.Di = src.Di; p.Hi = src.Hi; p.Wi = src.Wi; p.ldx = src.ldx; p.K = src.K;
         p.Gd = src.Gd; p.Gh = src.Gh; p.Gw = src.Gw; p.isd = src.isd; p.ish = src.ish; p.isw = src.isw;
         p.ldy = src.ldy; p.Nc = src.Nc; p.ksplit = src.ksplit; p.blk0 = src.blk0; p.tile0 = src.tile0; p.ntaps = src.ntaps;
+        p.pair = src.pair;
     }
 
     const long long M = (long long)p.N * p.Gd * p.Gh * p.Gw;
-    const int KT = (p.K + BM - 1) / BM, NT = (p.Nc + BN - 1) / BN;
+    const int KT = p.pair ? 1 : (p.K + BM - 1) / BM, NT = (p.Nc + BN - 1) / BN;
     // consecutive blocks are the cuts of one tile: with 8 cuts, cut c of every tile shares XCD c's L2 (speed only)
     const int local = (int)blockIdx.x - p.blk0;
     const int tile_local = local / p.ksplit;
@@ -263,7 +265,16 @@ __global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const W
     const int nt = b % NT; b /= NT;
     const int kt = b % KT;
     const int ti = b / KT;
-    const int tdd = g.p[pi].tap[ti][0], tdh = g.p[pi].tap[ti][1], tdw = g.p[pi].tap[ti][2], widx = g.p[pi].tap[ti][3];
+    // pair mode: the lanes that fetch the upper half of a row (channels 32-63 of the tile) belong to the second tap of the
+    // pair; a missing second tap (odd tap count) is sent out of range so that those lanes read the zero page
+    const int tA = p.pair ? 2 * ti : ti;
+    const bool upper = p.pair && (lane % (BM / 4)) >= BM / 8;
+    const int tL = upper ? tA + 1 : tA;                      // this LANE's tap
+    const bool tap_ok = tL < p.ntaps;
+    const int tLc = tap_ok ? tL : tA;
+    const int tdd = tap_ok ? (int)g.p[pi].tap[tLc][0] : 30000, tdh = g.p[pi].tap[tLc][1], tdw = g.p[pi].tap[tLc][2];
+    const int widx = g.p[pi].tap[tA][3];
+    const int widx2 = (p.pair && tA + 1 < p.ntaps) ? (int)g.p[pi].tap[tA + 1][3] : -1;
     const int k0 = kt * BM, n0 = nt * BN;
 
     long long chunk = (M + p.ksplit - 1) / p.ksplit;
@@ -390,9 +401,15 @@ __global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const W
 #pragma unroll 4
     for (int i = tid; i < BM * F4R; i += 256) {
         const int r = i / F4R, c4 = (i - r * F4R) * 4;
-        const int row = k0 + r, col = n0 + c4;
+        int row = k0 + r;
+        const int col = n0 + c4;
+        float* base = dwt;
+        if (p.pair) {
+            row = r & 31;
+            if (r >= 32) { if (widx2 < 0) continue; base = p.dw + (long long)widx2 * p.K * p.Nc; }
+        }
         if (row >= p.K || col >= p.Nc) continue;
-        float* dst = dwt + (long long)row * p.Nc + col;
+        float* dst = base + (long long)row * p.Nc + col;
         float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
         const float4 o = *reinterpret_cast<const float4*>(dst);
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -418,6 +435,10 @@ size_t lds_request(int tm, int tn) {
 }
 
 struct WPlan { int tm, tn; long long tiles; int ks; double cost; };
+long long tiles_of(const WgradArgs& a, int tm, int tn) {
+    if (a.pair) return (long long)((a.ntaps + 1) / 2) * ((a.Nc + tn - 1) / tn);
+    return (long long)a.ntaps * ((a.K + tm - 1) / tm) * ((a.Nc + tn - 1) / tn);
+}
 // Pick the tile and the number of position-range cuts with a small cost model: blocks run in rounds of
 // `slots` (256 CUs x resident blocks per CU), a round lasts (steps per block + fixed overhead) step-times; a 128x128 step
 // is ~3.2x a 64x64 step (4x the MFMAs, better LDS-DMA efficiency), a 64x128 / 128x64 step ~1.75x.  This avoids e.g. 540
@@ -429,7 +450,7 @@ WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
     auto best_for = [&](int TM_, int TN_) {
         WPlan w;
         w.tm = TM_; w.tn = TN_; w.ks = 1; w.cost = 1e300;
-        w.tiles = (long long)a.ntaps * ((a.K + TM_ - 1) / TM_) * ((a.Nc + TN_ - 1) / TN_);
+        w.tiles = tiles_of(a, TM_, TN_);
         // the model keeps 3 (2) slots per CU whatever the residency limit: with one resident block per CU the launch then
         // runs in ~3 short rounds, and short blocks are what lets main-stream blocks in (17.47 vs 17.78 ms / step)
         static const int per_cu = getenv("P3D_WGRAD_SLOTS") ? atoi(getenv("P3D_WGRAD_SLOTS")) : 0;
@@ -454,6 +475,7 @@ WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
     // the step 89.7 -> 87.6 ms (128x128: 87.0, but 17.34 vs 17.22 ms on the 16x112x112 step; 128x64: worse on both).  The
     // cut count still comes from the model above: a cost model of its own that counted work per CU picked fewer, longer
     // blocks and lost 0.2-3.6 ms per step on every workload although each filter gradient alone was faster.
+    if (a.pair) return best_for(64, 64);
     const bool busy = other_tiles == 0 && M > P3D_WGRAD_POLITE_ROWS && a.Nc >= 128 && getenv("P3D_WGRAD_NO_RECT") == nullptr &&
                       getenv("P3D_WGRAD_TILE") == nullptr;
     if (busy) return best_for(64, 128);
@@ -477,6 +499,7 @@ bool wgrad_ok(const WgradArgs& a) {
     if (M >= (1ll << 31) - 4096 || a.Gw > 400 || a.Gh > 400 || a.Gd > 400) return false;   // reciprocal carries
     if (a.ntaps > P3D_MAX_TAPS || a.stem_wfloats || !a.zeros) return false;
     if ((a.K & 3) || (a.ldx & 3) || (a.Nc & 3) || (a.ldy & 3)) return false;
+    if (a.pair && a.K > 32) return false;
     for (int t = 0; t < a.ntaps; ++t)
         if (a.taps[t].dd < -128 || a.taps[t].dd > 127 || a.taps[t].dh < -128 || a.taps[t].dh > 127 || a.taps[t].dw < -128 ||
             a.taps[t].dw > 127 || a.taps[t].widx < 0 || a.taps[t].widx > 127)
@@ -488,7 +511,7 @@ void fill_prob(WProb& p, const WgradArgs& a) {
     p.x = a.x; p.dy = a.dy; p.dw = a.dw; p.dbias = a.dbias;
     p.N = a.N; p.Di = a.Di; p.Hi = a.Hi; p.Wi = a.Wi; p.ldx = a.ldx; p.K = a.K;
     p.Gd = a.Gd; p.Gh = a.Gh; p.Gw = a.Gw; p.isd = a.isd; p.ish = a.ish; p.isw = a.isw;
-    p.ldy = a.ldy; p.Nc = a.Nc; p.ntaps = a.ntaps;
+    p.ldy = a.ldy; p.Nc = a.Nc; p.ntaps = a.ntaps; p.pair = a.pair;
     for (int t = 0; t < a.ntaps; ++t) {
         p.tap[t][0] = (signed char)a.taps[t].dd; p.tap[t][1] = (signed char)a.taps[t].dh;
         p.tap[t][2] = (signed char)a.taps[t].dw; p.tap[t][3] = (signed char)a.taps[t].widx;
@@ -549,16 +572,16 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
     const WPlan solo = live.size() == 1 ? plan(*live[0]) : WPlan{64, 64, 0, 1, 0.0};
     const int tm = solo.tm, tn = solo.tn;
     long long tiles64_all = 0;
-    for (auto* a : live) tiles64_all += (long long)a->ntaps * ((a->K + 63) / 64) * ((a->Nc + 63) / 64);
+    for (auto* a : live) tiles64_all += tiles_of(*a, 64, 64);
     long long blocks = 0;
     int tile0 = 0, kstride = 1;
     for (size_t q = 0; q < live.size(); ++q) {
         const WgradArgs& a = *live[q];
         WProb& p = g.p[q];
         fill_prob(p, a);
-        const long long my64 = (long long)a.ntaps * ((a.K + 63) / 64) * ((a.Nc + 63) / 64);
+        const long long my64 = tiles_of(a, 64, 64);
         const WPlan w = live.size() == 1 ? plan(a) : plan(a, tiles64_all - my64);
-        const long long tiles = (long long)a.ntaps * ((a.K + tm - 1) / tm) * ((a.Nc + tn - 1) / tn);
+        const long long tiles = tiles_of(a, tm, tn);
         p.ksplit = w.ks;
         p.blk0 = (int)blocks;
         p.tile0 = tile0;

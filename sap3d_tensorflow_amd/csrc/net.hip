@@ -743,6 +743,7 @@ struct p3d_handle {
                     wa.Gd = ga.Gd; wa.Gh = ga.Gh; wa.Gw = ga.Gw; wa.isd = ga.isd; wa.ish = ga.ish; wa.isw = ga.isw;
                     wa.dy = y->g; wa.ldy = y->ld; wa.Nc = Cout; wa.dw = dw4; wa.ksplit = 1;
                     wa.greedy = 1;                     // the last launch of the backward pass: the main stream is done
+                    wa.pair = K4 <= 32 ? 1 : 0;        // 28 floats per kernel row: two rows of the 7x7 kernel per 64-row tile
                     wa.ntaps = KH;
                     for (int kh = 0; kh < KH; ++kh) wa.taps[kh] = ga.taps[kh];
                     launch_wgrad(sc, wa);

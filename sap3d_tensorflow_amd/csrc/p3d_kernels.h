@@ -93,6 +93,7 @@ struct WgradArgs {
     int ksplit;           // (chosen by the launcher)
     int greedy;           // 1: launched when nothing else is running -- take every LDS slot (conv_wgrad2.hip, launch_group_t)
     int polite;           // 1: runs beside a chain of small launches whatever its own size -- one block per CU
+    int pair;             // 1 (K <= 32): two taps share a 64-row tile (the stem's 28-float kernel rows)
     int stem_wfloats, stem_wstep, stem_wpad;
     const float* zeros;   // zero page (wgrad2 only)
     int ntaps;
