@@ -373,7 +373,11 @@ __global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(cons
     const int per = (total_steps + nsplit - 1) / nsplit;
     const int s_begin = slice * per;
     const int s_end = min(total_steps, s_begin + per);
+#if defined(P3D_TUNE_NO_LOOP)               // tools/micro only: the fixed cost of a launch (prologue + epilogue, no K loop)
+    const int nsteps = 0;
+#else
     const int nsteps = max(s_end - s_begin, 0);
+#endif
 
     f32x16 acc[TM][TN];
 #pragma unroll

@@ -226,7 +226,11 @@ void on_side_stream(const Ctx& c, hipEvent_t ev, F&& f) {
     if (c.dry || !c.side || !ev) { f(c); return; }
     // timing diagnostic (WRONG RESULTS): P3D_TUNE_SKIP_SIDE=deconv,block1 drops the side-stream jobs queued during the backward of
     // ops whose name contains one of the substrings -- what that share of the filter gradients costs the step
-    static const char* skip = getenv("P3D_TUNE_SKIP_SIDE");
+    static const char* skip = [] {
+        const char* e = getenv("P3D_TUNE_SKIP_SIDE");
+        if (e) fprintf(stderr, "[p3d] P3D_TUNE_SKIP_SIDE=%s: filter gradients are being DROPPED -- timing diagnostic, every result of this process is wrong\n", e);
+        return e;
+    }();
     if (skip && c.bwd_op) {
         std::string pats(skip), name(c.bwd_op);
         size_t a = 0;
