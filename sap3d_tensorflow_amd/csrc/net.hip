@@ -658,12 +658,14 @@ struct p3d_handle {
         pw.flops = 2.0 * M * a.ntaps * (double)a.K * a.Nc;
         pw.bytes = 4.0 * (std::min(M * a.ntaps, side) * a.K + M * a.Nc + (double)a.ntaps * a.K * a.Nc);
         static const bool no_group = getenv("P3D_NO_WGRAD_GROUP") != nullptr;
+        static const int64_t flush_tiles = getenv("P3D_WGRAD_FLUSH_TILES") ? atol(getenv("P3D_WGRAD_FLUSH_TILES")) : 512;   // tuning: 256 -> 17.25 ms / step, 512 -> 17.0, 1024 with groups of 12 -> 17.1
         const bool alone = no_group || wgrad_tiles64(a) >= 256;      // fills the chip by itself (and may take 128x128 tiles)
         if (alone) flush_wgrads(c);
         wq.push_back(pw);
         int64_t tiles = 0;
         for (auto& q : wq) tiles += wgrad_tiles64(q.a);
-        if (alone || (int)wq.size() == P3D_WGRAD_GROUP || tiles >= 256) flush_wgrads(c);
+        static const int group_max = getenv("P3D_WGRAD_GROUP_MAX") ? std::max(1, std::min(P3D_WGRAD_GROUP, atoi(getenv("P3D_WGRAD_GROUP_MAX")))) : P3D_WGRAD_GROUP;
+        if (alone || (int)wq.size() >= group_max || tiles >= flush_tiles) flush_wgrads(c);
     }
     void flush_wgrads(const Ctx& c) {
         if (wq.empty() || c.dry) { wq.clear(); return; }
