@@ -601,7 +601,8 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
         polite |= a->polite != 0; force |= a->greedy != 0;
         max_m = std::max(max_m, (long long)a->N * a->Gd * a->Gh * a->Gw);
     }
-    const bool greedy = !polite && (force || max_m > P3D_WGRAD_POLITE_ROWS);
+    static const long long polite_rows = getenv("P3D_WGRAD_POLITE_ROWS") ? atoll(getenv("P3D_WGRAD_POLITE_ROWS")) : P3D_WGRAD_POLITE_ROWS;   // tuning
+    const bool greedy = !polite && (force || max_m > polite_rows);
     if (tm == 128) return tn == 128 ? launch_group_t<128, 128>(g, blocks, slabs, tile0, greedy, polite, s)
                                     : launch_group_t<128, 64>(g, blocks, slabs, tile0, greedy, polite, s);
     return tn == 128 ? launch_group_t<64, 128>(g, blocks, slabs, tile0, greedy, polite, s)
