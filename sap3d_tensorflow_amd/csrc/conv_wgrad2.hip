@@ -1,6 +1,7 @@
-// Pipelined weight-gradient kernel for gfx950 (see conv_wgrad.hip for the math and the reference
-// call sites; this is the same contraction,  dW[tap][k][n] += sum_m Xg[m+tap][k] * dY[m][n],
-// with the machinery of conv_igemm2.hip): both operands are [position][channel] rows exactly as
+// Weight gradient of the P3D convolutions on gfx950 (TF Conv3DBackpropFilterV2 behind tf.nn.conv3d / tf.layers.conv3d /
+// conv3d_transpose at reference p3d.py:19,24,86,112,125,172,200-217): for every kernel tap,
+//   dW[tap][k][n] += sum over the dense lattice m of  Xgathered[m + tap][k] * dY[m][n],
+// with the machinery of conv_igemm2.hip: both operands are [position][channel] rows exactly as
 // they lie in NDHWC memory, streamed global -> LDS by LDS-DMA into a 3-stage ring (one raw
 // s_barrier + one counted vmcnt per 32-position step), consumed by v_mfma_f32_32x32x2_f32 with
 // k = position.  Padded / out-of-range rows come from a zero page.

@@ -328,45 +328,6 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolArgs a) {
     }
 }
 
-// dx[argmax] += dy, first maximum in (kd,kh,kw) scan order.
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolArgs a) {
-    const int c4n = a.C >> 2;
-    const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * c4n;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        long long pos = i / c4n;
-        const int c = (int)(i - pos * c4n) << 2;
-        const long long opos = pos;
-        const int ow = (int)(pos % a.Wo); pos /= a.Wo;
-        const int oh = (int)(pos % a.Ho); pos /= a.Ho;
-        const int od = (int)(pos % a.Do); const int n = (int)(pos / a.Do);
-        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        long long arg[4] = {-1, -1, -1, -1};
-        for (int kd = 0; kd < a.kd; ++kd) {
-            const int id = od * a.sd - a.pd + kd;
-            if ((unsigned)id >= (unsigned)a.Di) continue;
-            for (int kh = 0; kh < a.kh; ++kh) {
-                const int ih = oh * a.sh - a.ph + kh;
-                if ((unsigned)ih >= (unsigned)a.Hi) continue;
-                for (int kw = 0; kw < a.kw; ++kw) {
-                    const int iw = ow * a.sw - a.pw + kw;
-                    if ((unsigned)iw >= (unsigned)a.Wi) continue;
-                    const long long ipos = (((long long)n * a.Di + id) * a.Hi + ih) * a.Wi + iw;
-                    const float4 v = ld4(a.x + ipos * a.ldx + c);
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (vv[q] > best[q]) { best[q] = vv[q]; arg[q] = ipos; }
-                }
-            }
-        }
-        const float4 g = ld4(a.dy + opos * a.lddy + c);
-        const float gg[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (arg[q] >= 0) unsafeAtomicAdd(a.dx + arg[q] * a.lddx + c + q, gg[q]);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* pred, const float* target, long long n,
                                                         double* loss_out, float* dl, int through_sigmoid, double* part,
@@ -714,12 +675,6 @@ hipError_t p3d_maxpool_bwd_disjoint(const PoolArgs& a, int accumulate, hipStream
     return hipGetLastError();
 }
 
-hipError_t p3d_maxpool_bwd(const PoolArgs& a, hipStream_t s) {
-    if (a.C & 3) return hipErrorInvalidValue;
-    const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * (a.C >> 2);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
 
 hipError_t p3d_smooth_l1(const float* pred, const float* target, long n, double* loss_out, float* dlogits,
                          int through_sigmoid, hipStream_t s) {

@@ -255,10 +255,7 @@ void launch_wgrad(const Ctx& c, const WgradArgs& a0) {
     const double side = (double)a.N * a.Di * a.Hi * a.Wi;
     const double fl = 2.0 * M * a.ntaps * (double)a.K * a.Nc;
     const double by = 4.0 * (std::min(M * a.ntaps, side) * a.K + M * a.Nc + (double)a.ntaps * a.K * a.Nc);
-    if (a.stem_wfloats) {
-        launch(c, p3d_wgrad_variant(a), fl, by, [&]() { return p3d_launch_wgrad(a, c.s); });
-        return;
-    }
+    if (a.stem_wfloats) throw P3dError("the 3-channel stem's filter gradient runs on its packed form (stem_filter_gradient)");
     a.zeros = g_zero_page;
     launch(c, p3d_wgrad2_variant(a), fl, by, [&]() { return p3d_launch_wgrad2(a, c.s); });
 }
@@ -381,6 +378,25 @@ std::vector<IgemmArgs> igemm_conv_input_side(const ConvGeo& g, int N, const floa
     return v;
 }
 
+// Filter gradient of the [1,kh,kw,3,Cout] stem conv on its packed form (conv(): "stem"): x4 is the 4-channel, W-padded copy
+// of the clip ([rows][Wp][4]), dw4 the packed gradient [kh][kw*4][Cout] (zeroed here); dw += its three real channels.
+void stem_filter_gradient(const Ctx& c, const ConvGeo& g, int N, int Wp, const float* x4, const float* dy, int ldy, int Cout, float* dw4,
+                          float* dw, float* dbias, bool greedy) {
+    const int KH = g.k[1], K4 = g.k[2] * 4;
+    if (!c.dry) HIPCHECK(hipMemsetAsync(dw4, 0, (size_t)KH * K4 * Cout * sizeof(float), c.s));
+    WgradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.x = x4; wa.N = N; wa.Di = g.I[0]; wa.Hi = g.I[1]; wa.Wi = Wp; wa.ldx = 4; wa.K = K4;
+    wa.Gd = g.O[0]; wa.Gh = g.O[1]; wa.Gw = g.O[2]; wa.isd = g.s[0]; wa.ish = g.s[1]; wa.isw = g.s[2];
+    wa.dy = dy; wa.ldy = ldy; wa.Nc = Cout; wa.dw = dw4; wa.dbias = dbias; wa.ksplit = 1;
+    wa.ntaps = KH;
+    for (int kh = 0; kh < KH; ++kh) { wa.taps[kh].dd = 0; wa.taps[kh].dh = (int16_t)(kh - g.pad[1]); wa.taps[kh].dw = 0; wa.taps[kh].widx = (int16_t)kh; }
+    wa.greedy = greedy ? 1 : 0;
+    wa.pair = K4 <= 32 ? 1 : 0;            // 28 floats per kernel row: two rows of the 7x7 kernel per 64-row tile
+    launch_wgrad(c, wa);
+    launch(c, "stem_unpack_dw_kernel", 0, 8.0 * KH * K4 * Cout, [&]() { return p3d_stem_unpack_dw(dw4, dw, KH * g.k[2], Cout, c.s); });
+}
+
 WgradArgs wgrad_conv(const ConvGeo& g, int N, const float* x, int ldx, int Cin, const float* dy, int ldy, int Cout,
                      float* dw, float* dbias, bool stem = false) {
     WgradArgs a;
@@ -389,10 +405,7 @@ WgradArgs wgrad_conv(const ConvGeo& g, int N, const float* x, int ldx, int Cin, 
     a.Gd = g.O[0]; a.Gh = g.O[1]; a.Gw = g.O[2];
     a.isd = g.s[0]; a.ish = g.s[1]; a.isw = g.s[2];
     a.dy = dy; a.ldy = ldy; a.Nc = Cout; a.dw = dw; a.dbias = dbias; a.ksplit = 1;
-    if (stem) {
-        stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
-        return a;
-    }
+    if (stem) throw P3dError("the 3-channel stem's filter gradient runs on its packed form (stem_filter_gradient)");
     int t = 0;
     for (int kd = 0; kd < g.k[0]; ++kd)
         for (int kh = 0; kh < g.k[1]; ++kh)
@@ -739,21 +752,8 @@ struct p3d_handle {
             };
             op.bwd = [=](const Ctx& c) {
                 on_side_stream(c, fork_ev, [=](const Ctx& sc) {
-                    if (!sc.dry) HIPCHECK(hipMemsetAsync(dw4, 0, (size_t)KH * K4 * Cout * sizeof(float), sc.s));
-                    IgemmArgs ga;
-                    memset(&ga, 0, sizeof(ga));
-                    geometry(ga);
-                    WgradArgs wa;
-                    memset(&wa, 0, sizeof(wa));
-                    wa.x = x4; wa.N = ga.N; wa.Di = ga.Di; wa.Hi = ga.Hi; wa.Wi = ga.Wi; wa.ldx = 4; wa.K = K4;
-                    wa.Gd = ga.Gd; wa.Gh = ga.Gh; wa.Gw = ga.Gw; wa.isd = ga.isd; wa.ish = ga.ish; wa.isw = ga.isw;
-                    wa.dy = y->g; wa.ldy = y->ld; wa.Nc = Cout; wa.dw = dw4; wa.ksplit = 1;
-                    wa.greedy = 1;                     // the last launch of the backward pass: the main stream is done
-                    wa.pair = K4 <= 32 ? 1 : 0;        // 28 floats per kernel row: two rows of the 7x7 kernel per 64-row tile
-                    wa.ntaps = KH;
-                    for (int kh = 0; kh < KH; ++kh) wa.taps[kh] = ga.taps[kh];
-                    launch_wgrad(sc, wa);
-                    launch(sc, "stem_unpack_dw_kernel", 0, 8.0 * KH * K4 * Cout, [&]() { return p3d_stem_unpack_dw(dw4, w->g, KH * g.k[2], Cout, sc.s); });
+                    // greedy: the last launch of the backward pass -- the main stream is done
+                    stem_filter_gradient(sc, g, x->N, Wp, x4, y->g, y->ld, Cout, dw4, w->g, nullptr, /*greedy=*/true);
                 });
                 if (xflag) throw P3dError("the stem input carries no gradient");
             };
@@ -1017,8 +1017,7 @@ struct p3d_handle {
                 launch(c, "maxpool_bwd_gather_kernel", 0, pool_bytes * 2, [&]() { return p3d_maxpool_bwd_gather(pa, *xflag, c.s); });
                 return;
             }
-            if (!*xflag) zero_strided(c, x->g, x->ld, x->rows(), x->C);
-            launch(c, "maxpool_bwd_kernel", 0, pool_bytes * 2, [&]() { return p3d_maxpool_bwd(pa, c.s); });
+            throw P3dError("max-pool with overlapping windows was built without its arg-max table");
         };
         ops.push_back(op);
         return out;
@@ -2681,9 +2680,20 @@ int p3d_op_conv3d_backprop_filter(int device, const float* x, const int64_t xs[5
     const int Cin = (int)xs[4], Cout = (int)ws[4];
     const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
     DevBuf dx(prod5(xs), x), dy(ny, dyh), dw(prod5(ws)), db(Cout);
-    WgradArgs a = wgrad_conv(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, dbh ? db.p : nullptr, is_stem_shape(xs, ws));
     ensure_zero_page();
-    { Ctx c; launch_wgrad(c, a); }
+    if (is_stem_shape(xs, ws)) {          // [1,kh,kw,3,Cout] on its packed form, like the network's stem (no atomics anywhere)
+        if (Cin != 3) throw P3dError("conv3d_backprop_filter: channel counts that are not multiples of 4 are supported for the 3-channel stem only");
+        const int pad_total = std::max((g.O[2] - 1) * g.s[2] + g.k[2] - g.I[2], 0), Wp = g.I[2] + pad_total;
+        const int64_t xrows = xs[0] * g.I[0] * g.I[1];
+        DevBuf x4(xrows * Wp * 4), dw4((int64_t)g.k[1] * g.k[2] * 4 * Cout);
+        Ctx c;
+        HIPCHECK(p3d_stem_pad(dx.p, x4.p, xrows, g.I[2], Wp, g.pad[2], c.s));
+        stem_filter_gradient(c, g, (int)xs[0], Wp, x4.p, dy.p, Cout, Cout, dw4.p, dw.p, dbh ? db.p : nullptr, false);
+        HIPCHECK(hipDeviceSynchronize());
+    } else {
+        WgradArgs a = wgrad_conv(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, dbh ? db.p : nullptr, false);
+        Ctx c; launch_wgrad(c, a);
+    }
     dw.get(dwh, prod5(ws));
     if (dbh) db.get(dbh, Cout);
     API_END
@@ -2736,10 +2746,16 @@ int p3d_op_max_pool3d_grad(int device, const float* x, const int64_t xs[5], cons
     HIPCHECK(hipSetDevice(device));
     const ConvGeo g = make_geo((int)xs[1], (int)xs[2], (int)xs[3], k, s);
     const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * xs[4];
-    DevBuf dx(prod5(xs), x), dy(ny, dyh), dg(prod5(xs));
+    if (xs[4] % 4) throw P3dError("max_pool3d_grad needs a channel count that is a multiple of 4");
+    DevBuf dx(prod5(xs), x), dy(ny, dyh), dg(prod5(xs)), yy(ny), tab(ny / 4);
     PoolArgs a = pool_args(xs, k, s, g);
-    a.x = dx.p; a.dy = dy.p; a.dx = dg.p;
-    HIPCHECK(p3d_maxpool_bwd(a, nullptr));
+    a.x = dx.p; a.dy = dy.p; a.dx = dg.p; a.y = yy.p;
+    const bool disjoint = p3d_maxpool_disjoint(a);
+    if (!disjoint) a.idx = reinterpret_cast<unsigned*>(tab.p);
+    HIPCHECK(p3d_maxpool_fwd(a, nullptr));       // the backward kernels read the forward's output (disjoint windows: the first
+                                                 // cell equal to the maximum) or its arg-max table (overlapping windows: a gather)
+    if (disjoint) HIPCHECK(p3d_maxpool_bwd_disjoint(a, 0, nullptr));
+    else HIPCHECK(p3d_maxpool_bwd_gather(a, 0, nullptr));
     dg.get(dxh, prod5(xs));
     API_END
 }

@@ -17,7 +17,7 @@
 
 #define P3D_MAX_TAPS 27
 #define P3D_WGRAD_GROUP 6     // weight-gradient problems one grouped launch can carry (kernel-argument space)
-#define P3D_STAT_REPLICAS 16   // per-channel accumulators are replicated to spread same-address atomics (backward reductions, GN)
+#define P3D_STAT_REPLICAS 16   // lanes that share a channel's partial sums in the finalize kernels (fixed 4-step shuffle fold)
 
 struct P3dTap {
     int16_t dd, dh, dw;   // gathered coordinate = g*is + d{d,h,w}
@@ -105,7 +105,6 @@ extern "C++" {
 #endif
 
 hipError_t p3d_launch_igemm(const IgemmArgs& a, hipStream_t s);
-hipError_t p3d_launch_wgrad(const WgradArgs& a, hipStream_t s);
 P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split);
 // Autotuning window (graph build): inside it, the first plan request for a new shape is decided by timing the
 // candidates on stream `s` with the caller's real buffers; outside it, a heuristic answers for unseen shapes.
@@ -114,7 +113,6 @@ void p3d_tune_end();
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipStream_t s);
 void p3d_igemm2_override(int tile, int splits, int xmap);   // tools/micro sweeps: -1 / 0 / -1 = no override
 const char* p3d_igemm_variant(const IgemmArgs& a);     // kernel symbol the launcher will pick
-const char* p3d_wgrad_variant(const WgradArgs& a);
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s);   // up to P3D_WGRAD_GROUP problems, one launch
 const char* p3d_wgrad2_variant(const WgradArgs& a);
@@ -290,7 +288,6 @@ hipError_t p3d_maxpool_fwd(const PoolArgs& a, hipStream_t s);
 // overlapping windows without atomics or a zero fill: every input cell collects from the (few) windows that contain it,
 // using the arg-max taps the forward stored.  Writes dx, or adds to it (accumulate = 1).
 hipError_t p3d_maxpool_bwd_gather(const PoolArgs& a, int accumulate, hipStream_t s);
-hipError_t p3d_maxpool_bwd(const PoolArgs& a, hipStream_t s);   // atomically adds into dx
 bool p3d_maxpool_disjoint(const PoolArgs& a);                    // k == s, no padding: windows do not overlap
 hipError_t p3d_maxpool_bwd_disjoint(const PoolArgs& a, int accumulate, hipStream_t s);   // writes / accumulates dx, no atomics
 
@@ -306,7 +303,7 @@ struct HeadArgs {
 };
 hipError_t p3d_head_fwd(const HeadArgs& a, hipStream_t s);
 hipError_t p3d_head_bwd_input(const HeadArgs& a, hipStream_t s);    // dx written
-hipError_t p3d_head_bwd_filter(const HeadArgs& a, hipStream_t s);   // dk, dbias atomically added
+hipError_t p3d_head_bwd_filter(const HeadArgs& a, hipStream_t s);   // dk, dbias += (per-block partials folded in block order)
 // the stride-1 variant tf.layers.conv3d(x, 1, 3, 1, 'same') (gn/p3d_gn.py:537): D,H,W are both input and output extents
 hipError_t p3d_headc_fwd(const HeadArgs& a, hipStream_t s);
 hipError_t p3d_headc_bwd_input(const HeadArgs& a, hipStream_t s);

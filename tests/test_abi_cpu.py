@@ -88,3 +88,17 @@ def test_product_never_imports_the_oracle():
     for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
         uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
         assert (not uses) or fn.name == "cpu_baseline", fn.name
+
+
+def test_no_floating_point_atomics_in_the_kernel_sources():
+    """every cross-block sum is folded in a fixed order.  The only atomics allowed in csrc/ are integer
+    ones (arrival tickets, the AUC histogram counters)."""
+    import glob
+    import re
+    bad = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "sap3d_tensorflow_amd", "csrc", "*"))):
+        for i, line in enumerate(open(f, errors="replace"), 1):
+            code = line.split("//")[0]
+            if re.search(r"unsafeAtomicAdd|atomicAdd\s*\(\s*(?!&cnt\[)|atomic_add_f|__hip_atomic_fetch_add\s*\([^,]*,\s*[^,]*[.f]", code):
+                bad.append("%s:%d: %s" % (os.path.basename(f), i, line.strip()))
+    assert not bad, bad
