@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libp3dhip.so")
-SOURCES = ["conv_igemm.hip", "conv_igemm2.hip", "conv_wgrad2.hip", "elementwise.hip", "bn_small.hip", "gn.hip", "cbam.hip", "head.hip", "attention.hip", "metrics.hip", "net.hip"]
+SOURCES = ["conv_igemm2.hip", "conv_wgrad2.hip", "elementwise.hip", "bn_small.hip", "gn.hip", "cbam.hip", "head.hip", "attention.hip", "metrics.hip", "net.hip"]
 HEADERS = [os.path.join(CSRC, "p3d_kernels.h"), os.path.join(CSRC, "det_reduce.h"), os.path.join(os.path.dirname(HERE), "include", "p3d_hip.h")]
 FLAGS = (["-DP3D_SETPRIO"] if os.environ.get("P3D_SETPRIO") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 

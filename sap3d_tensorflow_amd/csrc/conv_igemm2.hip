@@ -1,6 +1,7 @@
 // Pipelined implicit-GEMM convolution for gfx950 -- the workhorse of the P3D path (every conv /
-// conv-input-gradient / conv3d_transpose except the Cin=3 stem; reference p3d.py:19,24,86,112,125,
-// 200-216).  Same geometry contract as conv_igemm.hip (p3d_kernels.h), different machinery:
+// conv-input-gradient / conv3d_transpose, the Cin=3 stem on its packed 4-channel form included; reference
+// p3d.py:19,24,86,112,125,172,200-216).  The geometry contract is IgemmArgs (p3d_kernels.h): a dense output lattice and
+// an input lattice gathered through kernel taps.  Machinery:
 //
 //  * operands go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction)
 //    into a 3-stage ring; loads for step s+2 are in flight while step s is on the matrix cores;
@@ -699,7 +700,7 @@ hipError_t launch_plan(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t 
     if (M <= 0 || a.Nc <= 0) return hipSuccess;
     if (M >= (1ll << 31) || (long long)a.N * a.Di * a.Hi * a.Wi >= (1ll << 31)) return hipErrorInvalidValue;
     if (a.Gd * a.isd >= 1024 || a.Gh * a.ish >= 1024 || a.Gw * a.isw >= 1024) return hipErrorInvalidValue;   // packed coords
-    if (a.ntaps > P3D_MAX_TAPS || a.stem_wfloats) return hipErrorInvalidValue;
+    if (a.ntaps > P3D_MAX_TAPS) return hipErrorInvalidValue;
     if ((a.K & 3) || (a.ldx & 3) || !a.zeros) return hipErrorInvalidValue;
     if ((a.Nc & 3) || (a.ldy & 3)) return hipErrorInvalidValue;
     if (pl.splits > 1 && pl.splits > a.ntaps * ((a.K + BK - 1) / BK)) return hipErrorInvalidValue;

@@ -498,7 +498,7 @@ WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
 bool wgrad_ok(const WgradArgs& a) {
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     if (M >= (1ll << 31) - 4096 || a.Gw > 400 || a.Gh > 400 || a.Gd > 400) return false;   // reciprocal carries
-    if (a.ntaps > P3D_MAX_TAPS || a.stem_wfloats || !a.zeros) return false;
+    if (a.ntaps > P3D_MAX_TAPS || !a.zeros) return false;
     if ((a.K & 3) || (a.ldx & 3) || (a.Nc & 3) || (a.ldy & 3)) return false;
     if (a.pair && a.K > 32) return false;
     for (int t = 0; t < a.ntaps; ++t)

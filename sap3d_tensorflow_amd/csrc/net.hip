@@ -163,10 +163,6 @@ void launch_igemm(const Ctx& c, const IgemmArgs& a0, int allow_split = 0) {
     IgemmArgs a = a0;
     double fl, by;
     igemm_work(a, fl, by);
-    if (a.stem_wfloats) {
-        launch(c, p3d_igemm_variant(a), fl, by, [&]() { return p3d_launch_igemm(a, c.s); });
-        return;
-    }
     a.zeros = g_zero_page;
     const P3dIgemmPlan pl = p3d_igemm2_plan(a, allow_split);
     const char* name = pl.name;
@@ -202,7 +198,7 @@ void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld
     for (auto& a : v) {
         a.accum = accumulate ? 1 : 0;
         a.statpart = nullptr; a.stat_base = 0;
-        if (stats && stats->part && !a.stem_wfloats) {
+        if (stats && stats->part) {
             IgemmArgs t = a; t.zeros = g_zero_page;
             const P3dIgemmPlan pl = p3d_igemm2_plan(t, 1);
             const int mt = p3d_igemm2_mtiles(t, pl);
@@ -255,7 +251,6 @@ void launch_wgrad(const Ctx& c, const WgradArgs& a0) {
     const double side = (double)a.N * a.Di * a.Hi * a.Wi;
     const double fl = 2.0 * M * a.ntaps * (double)a.K * a.Nc;
     const double by = 4.0 * (std::min(M * a.ntaps, side) * a.K + M * a.Nc + (double)a.ntaps * a.K * a.Nc);
-    if (a.stem_wfloats) throw P3dError("the 3-channel stem's filter gradient runs on its packed form (stem_filter_gradient)");
     a.zeros = g_zero_page;
     launch(c, p3d_wgrad2_variant(a), fl, by, [&]() { return p3d_launch_wgrad2(a, c.s); });
 }
@@ -287,15 +282,28 @@ ConvGeo make_geo(int Di, int Hi, int Wi, const int k[3], const int s[3]) {
 
 inline int pmod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
 
-// firstconv1 (p3d.py:172): kd = 1, the kw x Cin run is contiguous in NDHWC, so a tap = kernel row kh.
-void stemify(const ConvGeo& g, int Cin, int& K, int& ntaps, P3dTap* taps, int& wfloats, int& wstep, int& wpad) {
+// firstconv1 (p3d.py:172) on its packed form: the clip is copied to 4 channels with the SAME padding of the W axis written out
+// (x4 [rows][Wp][4]), so that a kernel ROW is one tap of K = kw*4 contiguous floats (7 taps of K = 28 instead of 49 of K = 3).
+struct StemGeo { int Wp, K4, KH; int64_t xrows; };
+StemGeo stem_geo(const ConvGeo& g, int N) {
     if (g.k[0] != 1) throw P3dError("stem mode needs kd == 1");
-    K = g.k[2] * Cin;
-    ntaps = g.k[1];
-    for (int kh = 0; kh < g.k[1]; ++kh) {
-        taps[kh].dd = 0; taps[kh].dh = (int16_t)(kh - g.pad[1]); taps[kh].dw = 0; taps[kh].widx = (int16_t)kh;
-    }
-    wfloats = g.I[2] * Cin; wstep = g.s[2] * Cin; wpad = g.pad[2] * Cin;
+    StemGeo sg;
+    const int pad_total = std::max((g.O[2] - 1) * g.s[2] + g.k[2] - g.I[2], 0);
+    sg.Wp = g.I[2] + pad_total; sg.K4 = g.k[2] * 4; sg.KH = g.k[1];
+    sg.xrows = (int64_t)N * g.I[0] * g.I[1];
+    return sg;
+}
+IgemmArgs stem_forward_args(const ConvGeo& g, int N, const StemGeo& sg, const float* x4, const float* w4, float* y, int ldy, int Cout,
+                            const float* bias) {
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = N; a.Di = g.I[0]; a.Hi = g.I[1]; a.Wi = sg.Wp; a.ldx = 4; a.K = sg.K4;
+    a.Gd = g.O[0]; a.Gh = g.O[1]; a.Gw = g.O[2]; a.isd = g.s[0]; a.ish = g.s[1]; a.isw = g.s[2];
+    a.ntaps = sg.KH;
+    for (int kh = 0; kh < sg.KH; ++kh) { a.taps[kh].dd = 0; a.taps[kh].dh = (int16_t)(kh - g.pad[1]); a.taps[kh].dw = 0; a.taps[kh].widx = (int16_t)kh; }
+    a.x = x4; a.y = y; a.Do = g.O[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.ldy = ldy; a.Nc = Cout;
+    a.osd = a.osh = a.osw = 1; a.w = w4; a.bias = bias;
+    return a;
 }
 
 // ---- launch-argument builders on the shared geometry ---------------------------------------------
@@ -309,10 +317,7 @@ IgemmArgs igemm_conv_forward(const ConvGeo& g, int N, const float* x, int ldx, i
     a.y = y; a.Do = g.O[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.ldy = ldy; a.Nc = Cout;
     a.osd = a.osh = a.osw = 1;
     a.w = w; a.wT = 0; a.bias = bias; a.accum = accum;
-    if (stem) {
-        stemify(g, Cin, a.K, a.ntaps, a.taps, a.stem_wfloats, a.stem_wstep, a.stem_wpad);
-        return a;
-    }
+    if (stem) throw P3dError("the 3-channel stem runs on its packed form (stem_forward_args)");
     int t = 0;
     for (int kd = 0; kd < g.k[0]; ++kd)
         for (int kh = 0; kh < g.k[1]; ++kh)
@@ -724,27 +729,17 @@ struct p3d_handle {
             // firstconv1 (p3d.py:172) on the pipelined kernels: 4-channel, W-padded copy of the clip, kw*4 contiguous
             // floats per kernel row (elementwise.hip, "stem"); 7 taps of K = 28 instead of 49 taps of K = 3
             if (k[0] != 1 || Cin != 3 || bias) throw P3dError("stem path is for [1,kh,kw,3,C] kernels without bias");
-            const int pad_total = std::max((g.O[2] - 1) * g.s[2] + g.k[2] - g.I[2], 0);
-            const int Wp = g.I[2] + pad_total, K4 = g.k[2] * 4, KH = g.k[1];
-            const int64_t xrows = (int64_t)x->N * g.I[0] * g.I[1];
+            const StemGeo sg = stem_geo(g, x->N);
+            const int Wp = sg.Wp, K4 = sg.K4, KH = sg.KH;
+            const int64_t xrows = sg.xrows;
             float* x4 = dalloc<float>(xrows * Wp * 4);
             HIPCHECK(hipMemset(x4, 0, (size_t)xrows * Wp * 4 * sizeof(float)));
             float* w4 = dalloc<float>((int64_t)KH * K4 * Cout);
             float* dw4 = dalloc<float>((int64_t)KH * K4 * Cout);
-            auto geometry = [=](IgemmArgs& a) {
-                a.N = x->N; a.Di = g.I[0]; a.Hi = g.I[1]; a.Wi = Wp; a.ldx = 4; a.K = K4;
-                a.Gd = g.O[0]; a.Gh = g.O[1]; a.Gw = g.O[2]; a.isd = g.s[0]; a.ish = g.s[1]; a.isw = g.s[2];
-                a.ntaps = KH;
-                for (int kh = 0; kh < KH; ++kh) { a.taps[kh].dd = 0; a.taps[kh].dh = (int16_t)(kh - g.pad[1]); a.taps[kh].dw = 0; a.taps[kh].widx = (int16_t)kh; }
-            };
             op.fwd = [=](const Ctx& c) {
                 launch(c, "stem_pad_kernel", 0, 28.0 * x->rows(), [&]() { return p3d_stem_pad(x->p, x4, xrows, g.I[2], Wp, g.pad[2], c.s); });
                 launch(c, "stem_pack_w_kernel", 0, 8.0 * KH * K4 * Cout, [&]() { return p3d_stem_pack_w(w->p, w4, KH * g.k[2], Cout, c.s); });
-                IgemmArgs a;
-                memset(&a, 0, sizeof(a));
-                geometry(a);
-                a.x = x4; a.y = y->p; a.Do = g.O[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.ldy = y->ld; a.Nc = Cout;
-                a.osd = a.osh = a.osw = 1; a.w = w4;
+                const IgemmArgs a = stem_forward_args(g, x->N, sg, x4, w4, y->p, y->ld, Cout, nullptr);
                 std::vector<IgemmArgs> v{a};
                 BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
                 StatSink sink; if (sbn) sink = bn_sink(sbn);
@@ -2647,10 +2642,21 @@ int p3d_op_conv3d(int device, const float* x, const int64_t xs[5], const float* 
     const int Cin = (int)xs[4], Cout = (int)ws[4];
     const int64_t ny = xs[0] * g.O[0] * g.O[1] * g.O[2] * Cout;
     DevBuf dx(prod5(xs), x), dw(prod5(ws), w), dy(ny), db(Cout, bias);
-    IgemmArgs a = igemm_conv_forward(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, bias ? db.p : nullptr, 0,
-                                     is_stem_shape(xs, ws));
     ensure_zero_page();
-    { Ctx c; std::vector<IgemmArgs> v{a}; run_igemm_group(c, v, dy.p, Cout, ny / Cout, Cout, false, nullptr); }
+    Ctx c;
+    if (is_stem_shape(xs, ws)) {          // [1,kh,kw,3,Cout] on its packed form, like the network's stem
+        if (Cin != 3) throw P3dError("conv3d: channel counts that are not multiples of 4 are supported for the 3-channel stem only");
+        const StemGeo sg = stem_geo(g, (int)xs[0]);
+        DevBuf x4(sg.xrows * sg.Wp * 4), w4((int64_t)sg.KH * sg.K4 * Cout);
+        HIPCHECK(p3d_stem_pad(dx.p, x4.p, sg.xrows, g.I[2], sg.Wp, g.pad[2], c.s));
+        HIPCHECK(p3d_stem_pack_w(dw.p, w4.p, sg.KH * g.k[2], Cout, c.s));
+        std::vector<IgemmArgs> v{stem_forward_args(g, (int)xs[0], sg, x4.p, w4.p, dy.p, Cout, Cout, bias ? db.p : nullptr)};
+        run_igemm_group(c, v, dy.p, Cout, ny / Cout, Cout, false, nullptr);
+        HIPCHECK(hipDeviceSynchronize());
+    } else {
+        std::vector<IgemmArgs> v{igemm_conv_forward(g, (int)xs[0], dx.p, Cin, Cin, dy.p, Cout, Cout, dw.p, bias ? db.p : nullptr, 0, false)};
+        run_igemm_group(c, v, dy.p, Cout, ny / Cout, Cout, false, nullptr);
+    }
     dy.get(y, ny);
     API_END
 }
@@ -2683,9 +2689,10 @@ int p3d_op_conv3d_backprop_filter(int device, const float* x, const int64_t xs[5
     ensure_zero_page();
     if (is_stem_shape(xs, ws)) {          // [1,kh,kw,3,Cout] on its packed form, like the network's stem (no atomics anywhere)
         if (Cin != 3) throw P3dError("conv3d_backprop_filter: channel counts that are not multiples of 4 are supported for the 3-channel stem only");
-        const int pad_total = std::max((g.O[2] - 1) * g.s[2] + g.k[2] - g.I[2], 0), Wp = g.I[2] + pad_total;
-        const int64_t xrows = xs[0] * g.I[0] * g.I[1];
-        DevBuf x4(xrows * Wp * 4), dw4((int64_t)g.k[1] * g.k[2] * 4 * Cout);
+        const StemGeo sg = stem_geo(g, (int)xs[0]);
+        const int Wp = sg.Wp;
+        const int64_t xrows = sg.xrows;
+        DevBuf x4(xrows * Wp * 4), dw4((int64_t)sg.KH * sg.K4 * Cout);
         Ctx c;
         HIPCHECK(p3d_stem_pad(dx.p, x4.p, xrows, g.I[2], Wp, g.pad[2], c.s));
         stem_filter_gradient(c, g, (int)xs[0], Wp, x4.p, dy.p, Cout, Cout, dw4.p, dw.p, dbh ? db.p : nullptr, false);

@@ -47,12 +47,7 @@ struct IgemmArgs {
     int stat_base;
     int accum;            // 1: Y += result (gradient accumulation)
     int sigmoid;          // 1: store 1/(1+exp(-v)) (unused by the generic path today)
-    // stem mode (firstconv1, p3d.py:172): the W axis and the 3 input channels are
-    // one contiguous run; a "tap" is a kernel row kh and K = kw*Cin floats.
-    int stem_wfloats;     // Wi*Cin floats per input row (0 = not stem)
-    int stem_wstep;       // floats advanced per output column (sw*Cin)
-    int stem_wpad;        // floats of left padding (pad_w*Cin)
-    const float* zeros;   // >= 128 B of zeros in device memory (source for padded / tail lanes; igemm2 only)
+    const float* zeros;   // >= 128 B of zeros in device memory (source for padded / tail lanes)
     // K-slicing (filled by the launcher from the plan): slice s of a tile stores its partial tile to
     // slab[(tile * nsplit + s) * BM*BN], the block whose arrival ticket is the last one sums the slices in slice order
     // (bit-reproducible, unlike atomics), applies bias / accumulate / statistics and writes the output.
@@ -94,8 +89,7 @@ struct WgradArgs {
     int greedy;           // 1: launched when nothing else is running -- take every LDS slot (conv_wgrad2.hip, launch_group_t)
     int polite;           // 1: runs beside a chain of small launches whatever its own size -- one block per CU
     int pair;             // 1 (K <= 32): two taps share a 64-row tile (the stem's 28-float kernel rows)
-    int stem_wfloats, stem_wstep, stem_wpad;
-    const float* zeros;   // zero page (wgrad2 only)
+    const float* zeros;   // zero page
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
 };
@@ -104,7 +98,6 @@ struct WgradArgs {
 extern "C++" {
 #endif
 
-hipError_t p3d_launch_igemm(const IgemmArgs& a, hipStream_t s);
 P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split);
 // Autotuning window (graph build): inside it, the first plan request for a new shape is decided by timing the
 // candidates on stream `s` with the caller's real buffers; outside it, a heuristic answers for unseen shapes.
@@ -112,7 +105,6 @@ void p3d_tune_begin(hipStream_t s);
 void p3d_tune_end();
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipStream_t s);
 void p3d_igemm2_override(int tile, int splits, int xmap);   // tools/micro sweeps: -1 / 0 / -1 = no override
-const char* p3d_igemm_variant(const IgemmArgs& a);     // kernel symbol the launcher will pick
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s);   // up to P3D_WGRAD_GROUP problems, one launch
 const char* p3d_wgrad2_variant(const WgradArgs& a);
