@@ -56,3 +56,43 @@ def test_adam_trajectories_are_bit_identical(structure, cfg, shape):
     assert [l.tobytes() for l in finals[0][0]] == [l.tobytes() for l in finals[1][0]]
     for n, v in finals[0][1].items():
         assert np.array_equal(v, finals[1][1][n]), n
+
+
+def test_captured_step_graph_replays_the_eager_step_bit_for_bit():
+    """P3D_GRAPH=1 (opt-in): the train step captured into a hipGraph over three streams -- parked side-stream jobs, the
+    two-part optimiser step and the device-resident dropout seed / Adam step size included -- must give the eager
+    trajectory bit for bit.  The switch is read once per process, so both runs are child processes."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import p3d\n"
+        "from sap3d_tensorflow_amd import P3DSession\n"
+        "shape = (2, 16, 48, 48)\n"
+        "s = P3DSession('unet', batch=2, frames=16, height=48, width=48, base=16, blocks=(2, 2, 3), seed=3)\n"
+        "s.set_adam(1e-3)\n"
+        "s.upload(p3d.synthetic_clip(0, shape + (3,)), p3d.synthetic_target(3, shape))\n"
+        "losses = []\n"
+        "for i in range(4):\n"
+        "    s.train_step_device(0.5, seed=50 + i)\n"
+        "    losses.append(np.float32(s.last_loss()).tobytes().hex())\n"
+        "h = hashlib.sha256()\n"
+        "for n, _, _ in s.variables():\n"
+        "    h.update(s.get_param(n).tobytes())\n"
+        "print('RESULT', ' '.join(losses), h.hexdigest())\n"
+        "s.close()\n" % root)
+    outs = []
+    for graph in ("0", "1"):
+        env = dict(os.environ, P3D_GRAPH=graph)
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, r.stdout[-2000:]
+        outs.append(line[0])
+        if graph == "1":
+            assert "capture failed" not in r.stderr, r.stderr[-2000:]    # the capture must succeed, not quietly run eagerly
+    assert outs[0] == outs[1]
