@@ -87,3 +87,27 @@ def test_single_rank_allreduce_is_identity(structure):
     assert [a.tobytes() for a in l0] == [b.tobytes() for b in l1]
     for n in w0:
         assert np.array_equal(w0[n], w1[n]), n
+
+
+def test_bench_launch_path_with_two_ranks_on_one_gpu(tmp_path):
+    """The driver's multi-GPU command line (torch.distributed.run, one rank per GPU, rank 0 prints ONE JSON line), rehearsed on
+    a one-GPU box: P3D_BENCH_REHEARSAL=1 puts both ranks on device 0 and builds no RCCL communicator (RCCL refuses two ranks
+    on one device), so this covers the rendezvous, the barriers, the max-over-ranks timing and the output contract -- not the
+    all-reduce."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, P3D_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert "rehearsal" in out and out["value"] > 0 and np.isfinite(out["final_loss"])
+    for key in ("metric", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+        assert key in out
