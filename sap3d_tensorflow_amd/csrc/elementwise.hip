@@ -140,6 +140,74 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
     }
 }
 
+// BatchNorm finalize + apply in ONE launch for mid-size tensors (stage 2: 49-98 statistics partials per channel).  A block
+// owns 64 channels x a row chunk: it first folds the partials of ITS channels (4 lanes per channel, double accumulation,
+// fixed order -- every row chunk of a channel group computes the same bits), then normalises its rows.  No separate
+// bn_finalize launch on the forward chain; the blocks of row chunk 0 publish scale / shift / mean / invstd for the backward
+// pass and update the moving statistics.
+__device__ __forceinline__ void bn_fold64(const BnParams& bn, int c0, double invM, int use_batch, int update_moving, float eps, bool publish,
+                                          float* sc_lds, float* sh_lds) {
+    const int ch = c0 + (threadIdx.x >> 2), r = threadIdx.x & 3;
+    double s1 = 0.0, s2 = 0.0;
+    if (use_batch) {
+        const float2* part = reinterpret_cast<const float2*>(bn.statpart) + ch;
+#pragma unroll 8
+        for (int q = r; q < bn.nparts; q += 4) {
+            const float2 v = part[(size_t)q * bn.C];
+            s1 += (double)v.x; s2 += (double)v.y;
+        }
+        s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+        s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+    }
+    if (r) return;
+    double mean, var;
+    if (use_batch) {
+        mean = s1 * invM;
+        var = s2 * invM - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (publish && update_moving) {
+            bn.moving_mean[ch] -= (bn.moving_mean[ch] - (float)mean) * (1.0f - 0.99f);
+            bn.moving_var[ch] -= (bn.moving_var[ch] - (float)var) * (1.0f - 0.99f);
+        }
+    } else {
+        mean = bn.moving_mean[ch];
+        var = bn.moving_var[ch];
+    }
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)bn.gamma[ch] * inv);
+    const float sh = (float)((double)bn.beta[ch] - mean * (double)bn.gamma[ch] * inv);
+    sc_lds[ch - c0] = sc; sh_lds[ch - c0] = sh;
+    if (publish) { bn.scale[ch] = sc; bn.shift[ch] = sh; bn.mean[ch] = (float)mean; bn.invstd[ch] = (float)inv; }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_fold_apply_kernel(BnApplyArgs a, BnParams bn1, BnParams bn2, double invM, int batch1, int batch2,
+                                                           int update_moving, float eps, int rows_per_block) {
+    constexpr bool TWO = (MODE == 2 || MODE == 3);
+    __shared__ __attribute__((aligned(16))) float sc1[64], sh1[64], sc2[64], sh2[64];
+    const int c0 = blockIdx.y * 64;
+    const bool publish = blockIdx.x == 0;
+    bn_fold64(bn1, c0, invM, batch1, update_moving, eps, publish, sc1, sh1);
+    if (TWO) bn_fold64(bn2, c0, invM, batch2, update_moving, eps, publish, sc2, sh2);
+    __syncthreads();
+    const int cl = (threadIdx.x & 15) << 2, c = c0 + cl;
+    const float4 s1v = ld4(sc1 + cl), h1v = ld4(sh1 + cl);
+    float4 s2v = f4(0.f), h2v = f4(0.f);
+    if (TWO) { s2v = ld4(sc2 + cl); h2v = ld4(sh2 + cl); }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < a.M ? r0 + rows_per_block : a.M;
+    for (long long row = r0 + (threadIdx.x >> 4); row < r1; row += 16) {
+        const float4 v = fma4(s1v, ld4(a.y1 + row * a.ld1 + c), h1v);
+        float4 z;
+        if (MODE == 0) z = relu4(v);
+        else if (MODE == 1) z = relu4(add4(v, ld4(a.y2 + row * a.ld2 + c)));
+        else if (MODE == 2) z = relu4(add4(v, fma4(s2v, ld4(a.y2 + row * a.ld2 + c), h2v)));
+        else if (MODE == 3) z = add4(relu4(v), relu4(fma4(s2v, ld4(a.y2 + row * a.ld2 + c), h2v)));
+        else z = add4(ld4(a.y2 + row * a.ld2 + c), relu4(v));
+        st4(a.z + row * a.ldz + c, z);
+    }
+}
+
 // gradient entering BN1 / BN2 (after the ReLU gates) for one float4 of one row
 template <int MODE>
 __device__ __forceinline__ void bn_bwd_gates(const BnBwdArgs& a, long long row, int c, float4& g1, float4& g2,
@@ -541,6 +609,30 @@ hipError_t p3d_bn_apply(const BnApplyArgs& a, hipStream_t s) {
         case 4: hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(g), dim3(256), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+bool p3d_bn_fold_apply_ok(long M, int C, int nparts1, int nparts2, float drop_scale) {
+    static const bool off = getenv("P3D_BN_FOLD_APPLY") && atoi(getenv("P3D_BN_FOLD_APPLY")) == 0;      // A/B runs
+    return !off && (C % 64) == 0 && nparts1 <= 128 && nparts2 <= 128 && M >= 1024 && !(drop_scale > 0.f);
+}
+hipError_t p3d_bn_fold_apply(const BnApplyArgs& a, const BnParams& bn1, const BnParams& bn2, int batch1, int batch2, int update_moving,
+                             float eps, hipStream_t s) {
+    const bool two = a.mode == 2 || a.mode == 3;
+    if ((a.ld1 & 3) || (a.ldz & 3) || !p3d_bn_fold_apply_ok(a.M, a.C, batch1 ? bn1.nparts : 0, two && batch2 ? bn2.nparts : 0, a.drop_scale))
+        return hipErrorInvalidValue;
+    if ((batch1 && (!bn1.statpart || bn1.nparts < 1)) || (two && batch2 && (!bn2.statpart || bn2.nparts < 1))) return hipErrorInvalidValue;
+    const int groups = a.C / 64;
+    int chunks = 256 / groups;                         // ~256 blocks in all
+    if (chunks < 1) chunks = 1;
+    long rows = (a.M + chunks - 1) / chunks;
+    rows = (rows + 15) / 16 * 16;
+    chunks = (int)((a.M + rows - 1) / rows);
+    const dim3 g((unsigned)chunks, (unsigned)groups);
+    const double invM = 1.0 / (double)a.M;
+#define P3D_FA(M_) case M_: hipLaunchKernelGGL(bn_fold_apply_kernel<M_>, g, dim3(256), 0, s, a, bn1, bn2, invM, batch1, batch2, update_moving, eps, (int)rows); break;
+    switch (a.mode) { P3D_FA(0) P3D_FA(1) P3D_FA(2) P3D_FA(3) P3D_FA(4) default: return hipErrorInvalidValue; }
+#undef P3D_FA
     return hipGetLastError();
 }
 

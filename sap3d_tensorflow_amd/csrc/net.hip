@@ -929,8 +929,6 @@ struct p3d_handle {
                     return p3d_bn_finalize(bn_params(bn), M, bn->used_batch, bn->used_batch && c.update_moving, 1e-3f, c.s);
                 });
             };
-            fin(bn1);
-            if (two) fin(bn2);
             BnApplyArgs a;
             memset(&a, 0, sizeof(a));
             a.mode = mode; a.M = M; a.C = C;
@@ -939,6 +937,20 @@ struct p3d_handle {
             if (two) { a.scale2 = bn2->scale; a.shift2 = bn2->shift; }
             a.z = out->p; a.ldz = out->ld;
             if (dropout && c.training && c.drop > 0.f) { a.drop_rate = c.drop; a.drop_scale = 1.f / (1.f - c.drop); a.seed = c.seed; a.seed_dev = c.seed_dev; }
+            {   // few statistics partials per channel (stage 2): every apply block folds its own channels' -- one launch, not two or three
+                const bool b1 = bn1->follows_flag ? c.training : true, b2 = two ? (bn2->follows_flag ? c.training : true) : false;
+                if (!c.dry && p3d_bn_fold_apply_ok(M, C, b1 ? bn1->nparts : 0, b2 ? bn2->nparts : 0, a.drop_scale)) {
+                    bn1->used_batch = b1;
+                    if (two) bn2->used_batch = b2;
+                    const BnParams p1 = bn_params(bn1), p2 = two ? bn_params(bn2) : BnParams{};
+                    launch(c, "bn_fold_apply_kernel", 0, tens * (y2 ? 3 : 2), [&]() {
+                        return p3d_bn_fold_apply(a, p1, p2, b1, b2, c.update_moving ? 1 : 0, 1e-3f, c.s);
+                    });
+                    return;
+                }
+            }
+            fin(bn1);
+            if (two) fin(bn2);
             launch(c, kn_apply.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_apply(a, c.s); });
         };
         op.bwd = [=](const Ctx& c) {

@@ -143,6 +143,10 @@ struct BnApplyArgs {
     const unsigned long long* seed_dev;   // non-null: the seed is read from device memory (captured step graphs)
 };
 hipError_t p3d_bn_apply(const BnApplyArgs& a, hipStream_t s);
+// finalize + apply in one launch when every block can fold its own 64 channels' partials (<= 128 per BN, no dropout)
+bool p3d_bn_fold_apply_ok(long M, int C, int nparts1, int nparts2, float drop_scale);
+hipError_t p3d_bn_fold_apply(const BnApplyArgs& a, const BnParams& bn1, const BnParams& bn2, int batch1, int batch2, int update_moving,
+                             float eps, hipStream_t s);
 
 // Backward of the passes above.  Pass 1 reduces per channel sum(dz') and sum(dz' * xhat) into per-block
 // partials part1/part2; a finalize pass folds them in block order into coef1/coef2 ([C][2] floats: the two sums / M) and the parameter gradients; pass 2
