@@ -258,9 +258,15 @@ __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict_
                                           int kchunks, int wave, int lane, int wm, int wn, bool loads, bool computes) {
     constexpr int LPS = BM / 32 + BN / 32;
     constexpr bool LW = Loaders<BM, BN>::on;
+#if defined(P3D_TUNE_STAMPS)           // tools/micro only: shader-cycle stamps of block 0 / wave 0 (conv_chain.hip prints them)
+    const unsigned long long stamp0 = __builtin_readcyclecounter();
+#endif
     // loads of this step have landed for this wave; with a 3-stage ring the next step's may still fly
     if (!LW || loads) wait_vmcnt<(Ring<BM, BN>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();      // ... and for every wave; everyone is also done reading the stage refilled next
+#if defined(P3D_TUNE_STAMPS)
+    const unsigned long long stamp1 = __builtin_readcyclecounter();
+#endif
     if constexpr (LW) {
         if (loads) {
             issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
@@ -287,6 +293,12 @@ __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict_
     mfma_frags<BM, BN, WT, F16, 0, BK / 16>(f, acc);
     issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
     mfma_frags<BM, BN, WT, F16, BK / 16, BK / 8>(f, acc);
+#endif
+#if defined(P3D_TUNE_STAMPS)
+    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const unsigned long long stamp2 = __builtin_readcyclecounter();
+        atomicAdd(p.stamps + 0, stamp1 - stamp0); atomicAdd(p.stamps + 1, stamp2 - stamp1); atomicAdd(p.stamps + 2, 1ull);
+    }
 #endif
 }
 
@@ -341,6 +353,9 @@ __global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(cons
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
+#if defined(P3D_TUNE_STAMPS)
+    const unsigned long long kstamp0 = __builtin_readcyclecounter();
+#endif
     const long long M = (long long)p.N * p.Gd * p.Gh * p.Gw;
     const int NT = (p.Nc + BN - 1) / BN;
     const int nsplit = p.nsplit;
@@ -388,13 +403,26 @@ __global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(cons
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+#if defined(P3D_TUNE_STAMPS)
+    const unsigned long long kstampA = __builtin_readcyclecounter();     // after the output-row table
+#endif
     LoadState<LA, BN / 32> st;
     if (loads) loader_init<BM, BN, WT>(p, st, m0u, Mu, n0, wave, lane, s_begin, kchunks);
+#if defined(P3D_TUNE_STAMPS)
+    const unsigned long long kstampB = __builtin_readcyclecounter();     // after the loader's index arithmetic
+    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { atomicAdd(p.stamps + 6, kstampA - kstamp0); atomicAdd(p.stamps + 7, kstampB - kstampA); }
+#endif
     // prologue: STAGES-1 steps in flight; then step k computes from stage k % STAGES while refilling the stage
     // that was consumed one step earlier.  All stage addresses are compile-time constants (StepLoop).
     if (loads) PrologueLoop<BM, BN, WT, 0>::run(p, As, Bs, st, nsteps, kchunks, wave, lane);
+#if defined(P3D_TUNE_STAMPS)
+    const unsigned long long kstamp1 = __builtin_readcyclecounter();
+#endif
     for (int base = 0; base < nsteps; base += STAGES)
         StepLoop<BM, BN, WT, F16, 0>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn, loads, computes);
+#if defined(P3D_TUNE_STAMPS)
+    const unsigned long long kstamp2 = __builtin_readcyclecounter();
+#endif
 
     // ---- epilogue ----------------------------------------------------------------------------------
     // Stage the tile through LDS (the ring is free once the tail DMA has landed) so that global traffic is row-wise
@@ -527,6 +555,13 @@ __global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(cons
             dst[0] = t1; dst[1] = t2;
         }
     }
+#if defined(P3D_TUNE_STAMPS)
+    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long kstamp3 = __builtin_readcyclecounter();
+        atomicAdd(p.stamps + 3, kstamp1 - kstamp0); atomicAdd(p.stamps + 4, kstamp3 - kstamp2); atomicAdd(p.stamps + 5, 1ull);
+    }
+#endif
 }
 
 template <int BM, int BN>

@@ -57,6 +57,9 @@ struct IgemmArgs {
     int f16;              // 1: round the operand fragments to fp16 and use the fp16 MFMA (fp32 accumulate); pointwise convs of configs[4]
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
+#if defined(P3D_TUNE_STAMPS)     // tools/micro only: [0] cycles waiting for the stage (vmcnt + barrier), [1] rest of the steps, [2] steps,
+    unsigned long long* stamps;  // [3] prologue cycles, [4] epilogue cycles, [5] kernels -- summed by wave 0 of block 0
+#endif
 };
 
 // Tile and split-K choice of the pipelined kernel (conv_igemm2.hip)
