@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--size", type=int, default=112, help="clip height = width (BASELINE configs[4] uses 32 frames of 224)")
     ap.add_argument("--pointwise", default="fp32", choices=["fp32", "fp16"],
                     help="fp16: 1x1x1 convs on the fp16 MFMA with fp32 accumulate (BASELINE configs[4]); fp16-level parity")
+    ap.add_argument("--bn-fusion", default="on", choices=["on", "off"],
+                    help="off: every BatchNorm is a pass of its own (the round-2 launch list), for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--dump-launches", default=None, help="write every launch record of the profiled step to this CSV")
@@ -185,6 +187,8 @@ def main():
                       world_size=world, rank=rank, seed=1)
     if args.pointwise == "fp16":
         sess.set_pointwise_fp16(True)
+    if args.bn_fusion == "off":
+        sess.set_bn_fusion(False)
     if world > 1 and not rehearsal:
         sess.comm_init(plane.share_from_rank0(P3DSession.comm_unique_id))
     x = synthetic.synthetic_clip(rank, (B, T, S, S, 3))
@@ -244,6 +248,8 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "dropout": 0.5},
             "model_tflops": round(value * FLOP_PER_CLIP_FWD_BWD * (T / 16.0) * (S / 112.0) ** 2 / 1e12, 2) if args.structure == "unet" else None,
             "final_loss": loss,
+            "bn_fusion": args.bn_fusion,
+            "launches_per_step": len(recs),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
             "host_enqueue_ms_one_step_empty_queue": round(1e3 * t_one, 3),
             "roofline": roofline_of(rows),

@@ -106,6 +106,12 @@ int p3d_backward(p3d_handle* h, const float* x, const float* y, float dropout_ra
  * fp16-level (2e-2 relative on the saliency maps); the default, fp32, is the mode the 1e-3 target applies to. */
 int p3d_set_pointwise_fp16(p3d_handle* h, int enable);
 
+/* BatchNorm fusion (no reference counterpart: an execution choice, the arithmetic is tf.layers.batch_normalization's either
+ * way, p3d.py:56-81,88-97).  On (the default): the bn -> relu pairs between the convs of a bottleneck are applied on the
+ * operand paths of the neighbouring convolutions and never stored.  Off: every BatchNorm is a pass of its own (the
+ * round-2 launch list); kept for A/B timing and for parity tests of one path against the other. */
+int p3d_set_bn_fusion(p3d_handle* h, int enable);
+
 /* tf.train.AdamOptimizer(lr, beta1, beta2, epsilon) (train.py:168; defaults 1e-4, .9, .999, 1e-8). */
 int p3d_set_adam(p3d_handle* h, float lr, float beta1, float beta2, float eps);
 
@@ -159,6 +165,11 @@ int p3d_comm_init(p3d_handle* h, const void* id);
  * were handed over before their last producer had run (must be 0). */
 int p3d_debug_bucket_audit(p3d_handle* h, float dropout_rate, uint64_t seed, int64_t bucket_floats, int64_t* lo, int64_t* hi,
                            int32_t* after_op, int cap, int64_t* n_train, int64_t* stale);
+
+/* Test hook (process-wide): force the tile / K-slice plan of the convolution kernels where a problem allows it, so that
+ * every instantiation is reachable from the op-level parity tests.  igemm_tile: 0 = 64x64, 1 = 128x64, 2 = 128x128,
+ * -1 = the plan's choice; igemm_splits: K-slices, 0 = the plan's; wgrad_tm / wgrad_tn: 64 or 128, 0 = the plan's. */
+int p3d_debug_force_plan(int igemm_tile, int igemm_splits, int wgrad_tm, int wgrad_tn);
 
 /* ---- single operators on host arrays (the TF ops the path is made of), for op-level parity
  *      tests.  SAME padding, NDHWC, filters [kd,kh,kw,Cin,Cout]; strides s[3] = (sd,sh,sw). */

@@ -16,8 +16,21 @@
 //    slab and takes an arrival ticket; the block that draws the last ticket sums the slabs IN SLICE ORDER and
 //    writes the output (bias, accumulate and BatchNorm statistics included), so results are bit-reproducible --
 //    fp32 atomics were not (cdna_hip_programming.md, "Projection GEMM at M = 256", item 2);
+//  * FUSED BatchNorm (round 3; p3d.py:56-81,88-97).  The bn -> relu between two convs of a bottleneck is applied to the
+//    consumer conv's A operand on its way into LDS (template parameter AT, P3D_AT_*): the normalised tensor is never
+//    written or read.  The block builds the per-channel coefficient table in LDS in its prologue -- from the producer's per-tile
+//    statistics partials (fixed order, double accumulation) or from the published scale / shift; block 0 publishes
+//    scale / shift / mean / invstd for the backward pass and updates the moving statistics.  The A operand of these
+//    variants is staged through registers (plain global loads, transformed by the lane that fetched them, written to a
+//    two-slot LDS ring one step ahead of use; "fused BatchNorm" below), so padded taps stay exactly zero and the MFMA
+//    loop is the plain kernel's.  Input-gradient launches gate their result with the ReLU mask of the BatchNorm they
+//    differentiate through and leave (sum g, sum g*xhat) per tile (BnGate), so BatchNorm's backward needs no pass of
+//    its own either.
 //
 // fp32 in / fp32 accumulate: v_mfma_f32_32x32x2_f32, exact fp32 at the fp32 peak (157 TFLOP/s).
+#if !defined(__gfx950__) && !defined(__gfx942__) && defined(__HIP_DEVICE_COMPILE__)
+#error "the K-slice exchange (write-through slab stores + relaxed ticket + one-lane acquire) is written for gfx942 / gfx950 cache semantics"
+#endif
 #include "p3d_kernels.h"
 #include <algorithm>
 #include <cstdio>
@@ -33,33 +46,21 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BK = 32;
-#ifndef P3D_RING64
-#define P3D_RING64 3
-#endif
 template <int BM, int BN>
-struct Ring { static constexpr int stages = (BM >= 128) ? 2 : P3D_RING64; };   // 64x64: deep ring, few steps per K-slice
-// Loader waves (-DP3D_LW64=1; OFF: measured, no gain).  A 64x64 step costs 0.78 us; with the DMA issue compiled out it
-// costs 0.545 us, with the MFMAs compiled out 0.42 us (tools/micro/conv_chain.hip, -DP3D_TUNE_NO_DMA / _NO_MFMA), which
-// suggested that DMA issue (~150 cycles per global_load_lds in the issuing wave) and MFMA issue serialise in one wave's
-// instruction stream.  The 8-wave form below -- waves 0-3 only read fragments and issue MFMAs, waves 4-7 only wait for
-// and issue the LDS-DMA, one of each per SIMD, loaders leaving after the last step -- removes that serialisation, and
-// the step still costs 0.77 us (stage-3 shapes: 57.0 vs 58.4 us per launch at 72 steps; grouped filter gradients 43.9
-// vs 38.3 us, slower).  Deeper rings (4, 5 stages) change nothing either.  What is left is the matrix pipe itself on
-// real (non-zero) operands at the clock the chip holds under load: the DMA-free figure above ran on stale LDS contents.
-#ifndef P3D_LW64
-#define P3D_LW64 0
-#endif
-template <int BM, int BN>
-struct Loaders { static constexpr bool on = (BM == 64 && BN == 64 && P3D_LW64); static constexpr int threads = on ? 512 : 256; };
+struct Ring { static constexpr int stages = (BM >= 128) ? 2 : 3; };   // 64x64: deep ring, few steps per K-slice
+
+// operand transform traits
+template <int AT>
+struct ATr {
+    static constexpr bool two = (AT == P3D_AT_RELU2 || AT == P3D_AT_GRAD);          // second A source
+    static constexpr int ncoef = AT == P3D_AT_RELU1 ? 2 : AT == P3D_AT_RELU2 ? 4 : AT == P3D_AT_GRAD ? 3 : 0;
+};
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
     // LDS destination = wave-uniform base + lane * 16 B
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-
-template <int V>
-struct IC { static constexpr int value = V; };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -68,31 +69,37 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // Per-lane loader state, all in registers (an LDS read in the load path would make hipcc drain the
 // in-flight LDS-DMA first).  Row pointers are rebuilt only when the kernel tap changes; within a
-// tap a step just advances 32 floats along the channel run.
-template <int LA, int LB>
-struct LoadState {
+// tap a step just advances 32 floats along the channel run.  The A and the B operand have cursors of
+// their own: the fused-BatchNorm path fetches A one step further ahead than B.
+template <int LA, bool TWO>
+struct ALoad {
     int base[LA];            // n * Di*Hi*Wi, or -1 for rows past M
     int dhw[LA];             // (g_d*is_d) << 20 | (g_h*is_h) << 10 | (g_w*is_w)
     const float* aptr[LA];   // row start for the current tap (+ this lane's 16-byte chunk), null when padded
+    const float* aptr2[TWO ? LA : 1];   // same row of the second source
     int achunk[LA];          // 4 * logical chunk held by this lane's slot
-    int boff[LB];            // weight element offset of this lane's piece within a tap slab (k0 = 0)
-    int bk[LB];              // WT: 4 * logical chunk; !WT: k row within the step
-    bool bok[LB];            // n inside Nc
-    const float* wt;         // slab of the current tap
     int t, kc;               // next step to issue: tap index, k-chunk index
     int issued;              // steps issued so far
 };
+template <int LB>
+struct BLoad {
+    int boff[LB];            // weight element offset of this lane's piece within a tap slab (k0 = 0)
+    int bk[LB];              // WT: 4 * logical chunk; !WT: k row within the step
+    bool bok[LB];            // n inside Nc
+    int t, kc, issued;
+};
 
-template <int BM, int BN, bool WT>
-__device__ __forceinline__ void loader_init(const IgemmArgs& p, LoadState<BM / 32, BN / 32>& st, unsigned m0, unsigned M,
-                                            int n0, int wave, int lane, int s_begin, int kchunks) {
-    constexpr int LA = BM / 32, LB = BN / 32;
+template <int BM, bool TWO>
+__device__ __forceinline__ void a_init(const IgemmArgs& p, ALoad<BM / 32, TWO>& st, unsigned m0, unsigned M, int wave, int lane,
+                                       int s_begin, int kchunks) {
+    constexpr int LA = BM / 32;
     const int a_slot = lane & 7, a_sub = lane >> 3;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int r = (i * 4 + wave) * 8 + a_sub;
         const unsigned m = m0 + r;
         st.base[i] = -1; st.dhw[i] = 0; st.aptr[i] = nullptr;
+        if (TWO) st.aptr2[TWO ? i : 0] = nullptr;
         st.achunk[i] = 4 * (a_slot ^ ((r >> 1) & 7));
         if (m < M) {
             const unsigned gw = m % (unsigned)p.Gw; unsigned t = m / (unsigned)p.Gw;
@@ -102,6 +109,12 @@ __device__ __forceinline__ void loader_init(const IgemmArgs& p, LoadState<BM / 3
             st.dhw[i] = (int)(((gd * p.isd) << 20) | ((gh * p.ish) << 10) | (gw * p.isw));
         }
     }
+    st.t = s_begin / kchunks; st.kc = s_begin - st.t * kchunks; st.issued = 0;
+}
+template <int BN, bool WT>
+__device__ __forceinline__ void b_init(const IgemmArgs& p, BLoad<BN / 32>& st, int n0, int wave, int lane, int s_begin, int kchunks) {
+    constexpr int LB = BN / 32;
+    const int a_slot = lane & 7, a_sub = lane >> 3;
     if (!WT) {
         constexpr int LANES_PER_ROW = BN / 4, ROWS_PER_PIECE = 64 / LANES_PER_ROW;
 #pragma unroll
@@ -119,33 +132,33 @@ __device__ __forceinline__ void loader_init(const IgemmArgs& p, LoadState<BM / 3
             st.boff[i] = (n0 + r) * p.K + st.bk[i];
         }
     }
-    st.t = s_begin / kchunks; st.kc = s_begin - st.t * kchunks; st.issued = 0; st.wt = p.w;
+    st.t = s_begin / kchunks; st.kc = s_begin - st.t * kchunks; st.issued = 0;
 }
 
-template <int LA, int LB>
-__device__ __forceinline__ void loader_set_tap(const IgemmArgs& p, LoadState<LA, LB>& st) {
+template <int LA, bool TWO>
+__device__ __forceinline__ void a_set_tap(const IgemmArgs& p, ALoad<LA, TWO>& st) {
     const P3dTap tap = p.taps[st.t];
-    st.wt = p.w + (long long)tap.widx * p.K * p.Nc;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int id = (st.dhw[i] >> 20) + tap.dd, ih = ((st.dhw[i] >> 10) & 1023) + tap.dh, iw = (st.dhw[i] & 1023) + tap.dw;
         const bool ok = st.base[i] >= 0 && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
                         (unsigned)iw < (unsigned)p.Wi;
-        st.aptr[i] = ok ? p.x + ((long long)st.base[i] + ((long long)id * p.Hi + ih) * p.Wi + iw) * p.ldx + st.achunk[i] : nullptr;
+        const long long row = (long long)st.base[i] + ((long long)id * p.Hi + ih) * p.Wi + iw;
+        st.aptr[i] = ok ? p.x + row * p.ldx + st.achunk[i] : nullptr;
+        if (TWO) st.aptr2[TWO ? i : 0] = ok ? p.x2 + row * p.ldx2 + st.achunk[i] : nullptr;
     }
 }
 
-// Issue the LDS-DMA of the next (tap, k-chunk) step -- ALWAYS the same number of loads, so the counted
-// vmcnt never changes; steps past the end of this block's slice fetch the zero page.  a_dst / b_dst are
-// __restrict__ so that, inlined next to compute_stage, hipcc knows the fragment reads cannot alias the DMA
+// Issue the LDS-DMA of the next (tap, k-chunk) step of one operand -- ALWAYS the same number of loads, so the counted
+// vmcnt never changes; steps past the end of this block's slice fetch the zero page.  The destinations are
+// __restrict__ so that, inlined next to the fragment reads, hipcc knows the reads cannot alias the DMA
 // targets and does not put s_waitcnt vmcnt(0) in front of them.
-template <int BM, int BN, bool WT>
-__device__ __forceinline__ void issue_stage(const IgemmArgs& p, float* __restrict__ a_dst, float* __restrict__ b_dst,
-                                            LoadState<BM / 32, BN / 32>& st, int nsteps, int kchunks, bool first, int wave,
-                                            int lane) {
-    constexpr int LA = BM / 32, LB = BN / 32;
+template <int BM>
+__device__ __forceinline__ void issue_a_dma(const IgemmArgs& p, float* __restrict__ a_dst, ALoad<BM / 32, false>& st, int nsteps,
+                                            int kchunks, bool first, int wave, int lane) {
+    constexpr int LA = BM / 32;
     const bool live = st.issued < nsteps;
-    if (live && (first || st.kc == 0)) loader_set_tap(p, st);      // wave-uniform, once per tap
+    if (live && (first || st.kc == 0)) a_set_tap(p, st);      // wave-uniform, once per tap
     const int k0 = st.kc * BK;
     const float* zp = p.zeros + 4 * (lane & 7);
 #pragma unroll
@@ -153,31 +166,122 @@ __device__ __forceinline__ void issue_stage(const IgemmArgs& p, float* __restric
         const bool ok = live && st.aptr[i] != nullptr && (k0 + st.achunk[i]) < p.K;
         glds16(ok ? st.aptr[i] + k0 : zp, a_dst + (i * 4 + wave) * 8 * BK);
     }
+    ++st.issued;
+    if (++st.kc == kchunks) { st.kc = 0; ++st.t; }
+}
+template <int BN, bool WT>
+__device__ __forceinline__ void issue_b_dma(const IgemmArgs& p, float* __restrict__ b_dst, BLoad<BN / 32>& st, int nsteps, int kchunks,
+                                            int wave, int lane) {
+    constexpr int LB = BN / 32;
+    const bool live = st.issued < nsteps;
+    const int k0 = st.kc * BK;
+    const float* zp = p.zeros + 4 * (lane & 7);
+    const float* wt = p.w + (long long)p.taps[live ? st.t : 0].widx * p.K * p.Nc;
     if (!WT) {
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const bool ok = live && st.bok[i] && (k0 + st.bk[i]) < p.K;
-            glds16(ok ? st.wt + (long long)k0 * p.Nc + st.boff[i] : zp, b_dst + (i * 4 + wave) * 256);
+            glds16(ok ? wt + (long long)k0 * p.Nc + st.boff[i] : zp, b_dst + (i * 4 + wave) * 256);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const bool ok = live && st.bok[i] && (k0 + st.bk[i]) < p.K;
-            glds16(ok ? st.wt + k0 + st.boff[i] : zp, b_dst + (i * 4 + wave) * 8 * BK);
+            glds16(ok ? wt + k0 + st.boff[i] : zp, b_dst + (i * 4 + wave) * 8 * BK);
         }
     }
     ++st.issued;
     if (++st.kc == kchunks) { st.kc = 0; ++st.t; }
 }
 
+// ---- fused BatchNorm: the A operand takes a detour through raw LDS slots ---------------------------------------------
+// A lane DMAs the same 16-byte chunks as in the plain kernel (of one or two source tensors) into RAW slots, STAGES
+// steps ahead; one step before a chunk is consumed the lane that fetched it reads it back (its own bytes: no barrier
+// needed, only its own vmcnt), applies the per-channel transform -- that lane knows whether the chunk was a padded tap
+// or a row past the end, those stay exactly zero -- and writes the result to the chunk's place in a two-slot ring of
+// transformed tiles.  Fragment reads and MFMAs are those of the plain kernel, every A element is transformed once per
+// block (not once per wave that reads it), and the transform's few LDS / VALU instructions sit between the two MFMA
+// halves of a step.
+struct AMeta {
+    unsigned ok;             // bit i: chunk i is a real element run (else it stays zero)
+    int k0;                  // channel base of the step (coefficient table offset)
+};
+template <int BM, int AT>
+__device__ __forceinline__ void issue_a_raw(const IgemmArgs& p, float* __restrict__ raw_dst, float* __restrict__ raw2_dst, AMeta& r,
+                                            ALoad<BM / 32, ATr<AT>::two>& st, int nsteps, int kchunks, bool first, int wave, int lane) {
+    constexpr int LA = BM / 32;
+    constexpr bool TWO = ATr<AT>::two;
+    const bool live = st.issued < nsteps;
+    if (live && (first || st.kc == 0)) a_set_tap(p, st);
+    const int k0 = st.kc * BK;
+    const float* zp = p.zeros + 4 * (lane & 7);
+    r.ok = 0; r.k0 = k0;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const bool ok = live && st.aptr[i] != nullptr && (k0 + st.achunk[i]) < p.K;
+        r.ok |= (ok ? 1u : 0u) << i;
+        // always one DMA per chunk and source (the counted vmcnt): padded chunks read the zero page
+        glds16(ok ? st.aptr[i] + k0 : zp, raw_dst + (i * 4 + wave) * 8 * BK);
+        if (TWO) glds16(ok ? st.aptr2[TWO ? i : 0] + k0 : zp, raw2_dst + (i * 4 + wave) * 8 * BK);
+    }
+    ++st.issued;
+    if (++st.kc == kchunks) { st.kc = 0; ++st.t; }
+}
+__device__ __forceinline__ float4 relu_affine4(float4 s, float4 u, float4 t) {
+    return make_float4(fmaxf(fmaf(s.x, u.x, t.x), 0.f), fmaxf(fmaf(s.y, u.y, t.y), 0.f), fmaxf(fmaf(s.z, u.z, t.z), 0.f),
+                       fmaxf(fmaf(s.w, u.w, t.w), 0.f));
+}
+// The transform in two parts: the LDS reads (the lane's raw chunk(s) and its channels' coefficients) are issued with the
+// step's fragment reads, the arithmetic and the store of the transformed chunk run between the MFMA halves, when the data
+// has long arrived -- a wait there would idle the matrix pipe (one wave per SIMD: nothing else fills it).
+template <int LA, int AT>
+struct XIn {
+    float4 u[LA];
+    float4 v[ATr<AT>::two ? LA : 1];
+    float4 c[LA][ATr<AT>::ncoef];
+};
+template <int BM, int AT>
+__device__ __forceinline__ void transform_load(const AMeta& r, const float* __restrict__ raw_src, const float* __restrict__ raw2_src,
+                                               const int (&achunk)[BM / 32], const float* __restrict__ tab, int kp,
+                                               XIn<BM / 32, AT>& x, int wave, int lane) {
+    constexpr int LA = BM / 32;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int at = (i * 4 + wave) * 8 * BK + lane * 4;      // this lane's chunk: where its DMA put it, where the tile wants it
+        x.u[i] = *reinterpret_cast<const float4*>(raw_src + at);
+        if (ATr<AT>::two) x.v[ATr<AT>::two ? i : 0] = *reinterpret_cast<const float4*>(raw2_src + at);
+        const float* c = tab + r.k0 + achunk[i];
+#pragma unroll
+        for (int q = 0; q < ATr<AT>::ncoef; ++q) x.c[i][q] = *reinterpret_cast<const float4*>(c + q * kp);
+    }
+}
+template <int BM, int AT>
+__device__ __forceinline__ void transform_store(const AMeta& r, const XIn<BM / 32, AT>& x, float* __restrict__ a_dst, int wave, int lane) {
+    constexpr int LA = BM / 32;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int at = (i * 4 + wave) * 8 * BK + lane * 4;
+        const float4 u = x.u[i];
+        float4 a;
+        if constexpr (AT == P3D_AT_RELU1) {
+            a = relu_affine4(x.c[i][0], u, x.c[i][1]);
+        } else if constexpr (AT == P3D_AT_RELU2) {
+            const float4 p1 = relu_affine4(x.c[i][0], u, x.c[i][1]);
+            const float4 p2 = relu_affine4(x.c[i][2], x.v[i], x.c[i][3]);
+            a = make_float4(p1.x + p2.x, p1.y + p2.y, p1.z + p2.z, p1.w + p2.w);
+        } else {
+            const float4 v = x.v[i], k1 = x.c[i][0], k2 = x.c[i][1], k3 = x.c[i][2];
+            a = make_float4(fmaf(k1.x, u.x, fmaf(k2.x, v.x, k3.x)), fmaf(k1.y, u.y, fmaf(k2.y, v.y, k3.y)),
+                            fmaf(k1.z, u.z, fmaf(k2.z, v.z, k3.z)), fmaf(k1.w, u.w, fmaf(k2.w, v.w, k3.w)));
+        }
+        if (!((r.ok >> i) & 1u)) a = make_float4(0.f, 0.f, 0.f, 0.f);      // SAME padding, rows past M, channel tails
+        *reinterpret_cast<float4*>(a_dst + at) = a;
+    }
+}
+
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f16x4 to_half4(float4 v) { f16x4 r = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; return r; }
 
-// F16: the pointwise-conv option of BASELINE configs[4] -- operands stay fp32 in HBM and LDS, the fragments are
-// rounded to fp16 in registers and one v_mfma_f32_32x32x8_f16 (fp32 accumulate) replaces four fp32 MFMAs: a lane's
-// float4 fragment holds k = 8c + 4h + {0..3}, which is exactly the A / B operand layout of that instruction.
-// c-iterations [C0, C1) of one stage (BK / 8 = 4 in all): the stage is consumed in two halves so that the address
-// arithmetic and DMA issue of the next refill can run while the first half's MFMAs execute (pipe_step).
 // Fragments of one whole stage (BK / 8 = 4 c-iterations): every ds_read of the step is issued BEFORE the first MFMA, so
 // the LDS latency is paid once per step instead of once per c-iteration (each 32x32x2 MFMA chain on one accumulator is
 // 4 x 64 cycles: with the reads interleaved the matrix pipe idled ~120 cycles in every 256).
@@ -248,152 +352,226 @@ __device__ __forceinline__ void mfma_frags(const Frags<BM, BN, WT>& f, f32x16 (&
     }
 }
 
-// One pipeline step with COMPILE-TIME stage addresses and restrict-qualified views of the ring.
+template <int BM, int BN, int AT>
+struct Lds {      // float offsets inside the ring region
+    static constexpr int STAGES = Ring<BM, BN>::stages;
+    static constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN;
+    static constexpr int A_SLOTS = AT ? 2 : STAGES;                            // fused: transformed tiles, written one step ahead
+    static constexpr int B_OFF = A_SLOTS * A_STAGE;
+    static constexpr int RAW_SLOTS = AT ? STAGES - 1 : 0;                      // fused: raw DMA targets, per source
+    static constexpr int RAW_OFF = B_OFF + STAGES * B_STAGE;
+    static constexpr int RAW2_OFF = RAW_OFF + RAW_SLOTS * A_STAGE;
+    static constexpr int RING = RAW2_OFF + (ATr<AT>::two ? RAW_SLOTS * A_STAGE : 0);
+    static constexpr int TILE = BM * (BN + 4) + 2 * 4 * BN * 2 + 4;            // staged tile + statistics exchange (two gates) + reducer flag
+    static constexpr int FIXED = RING > TILE ? RING : TILE;                    // the coefficient table follows
+};
+
+// One pipeline step of the plain kernel with COMPILE-TIME stage addresses and restrict-qualified views of the ring.
 // Branch-free: wait for this step's loads, barrier, read the stage's fragments, first half of the MFMAs, issue step+2,
 // second half.
 template <int BM, int BN, bool WT, bool F16>
 __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict__ a_dst, float* __restrict__ b_dst,
                                           const float* __restrict__ a_src, const float* __restrict__ b_src,
-                                          f32x16 (&acc)[BM / 64][BN / 64], LoadState<BM / 32, BN / 32>& st, int nsteps,
-                                          int kchunks, int wave, int lane, int wm, int wn, bool loads, bool computes) {
+                                          f32x16 (&acc)[BM / 64][BN / 64], ALoad<BM / 32, false>& sa, BLoad<BN / 32>& sb, int nsteps,
+                                          int kchunks, int wave, int lane, int wm, int wn) {
     constexpr int LPS = BM / 32 + BN / 32;
-    constexpr bool LW = Loaders<BM, BN>::on;
-#if defined(P3D_TUNE_STAMPS)           // tools/micro only: shader-cycle stamps of block 0 / wave 0 (conv_chain.hip prints them)
-    const unsigned long long stamp0 = __builtin_readcyclecounter();
-#endif
     // loads of this step have landed for this wave; with a 3-stage ring the next step's may still fly
-    if (!LW || loads) wait_vmcnt<(Ring<BM, BN>::stages - 2) * LPS>();
+    wait_vmcnt<(Ring<BM, BN>::stages - 2) * LPS>();
     __builtin_amdgcn_s_barrier();      // ... and for every wave; everyone is also done reading the stage refilled next
-#if defined(P3D_TUNE_STAMPS)
-    const unsigned long long stamp1 = __builtin_readcyclecounter();
-#endif
-    if constexpr (LW) {
-        if (loads) {
-            issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
-        } else {
-            Frags<BM, BN, WT> f;
-            load_frags<BM, BN, WT>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_frags<BM, BN, WT, F16, 0, BK / 8>(f, acc);
-        }
-        (void)computes;
-        return;
-    }
     Frags<BM, BN, WT> f;
     load_frags<BM, BN, WT>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
     __builtin_amdgcn_sched_barrier(0);      // keep every read above the MFMAs (hipcc otherwise sinks half of them back)
-#if defined(P3D_TUNE_NO_MFMA)               // tools/micro only: what does a step cost without the matrix work / without the DMA
-    acc[0][0][0] += f.a[0][0].x * f.b[0][0].x + f.a[BK / 8 - 1][0].w * f.b[BK / 8 - 1][0].w;
-    issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
-#elif defined(P3D_TUNE_NO_DMA)
     mfma_frags<BM, BN, WT, F16, 0, BK / 16>(f, acc);
-    ++st.issued; if (++st.kc == kchunks) { st.kc = 0; ++st.t; }
+    issue_a_dma<BM>(p, a_dst, sa, nsteps, kchunks, false, wave, lane);
+    issue_b_dma<BN, WT>(p, b_dst, sb, nsteps, kchunks, wave, lane);
     mfma_frags<BM, BN, WT, F16, BK / 16, BK / 8>(f, acc);
-#else
-    mfma_frags<BM, BN, WT, F16, 0, BK / 16>(f, acc);
-    issue_stage<BM, BN, WT>(p, a_dst, b_dst, st, nsteps, kchunks, false, wave, lane);
-    mfma_frags<BM, BN, WT, F16, BK / 16, BK / 8>(f, acc);
-#endif
-#if defined(P3D_TUNE_STAMPS)
-    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        const unsigned long long stamp2 = __builtin_readcyclecounter();
-        atomicAdd(p.stamps + 0, stamp1 - stamp0); atomicAdd(p.stamps + 1, stamp2 - stamp1); atomicAdd(p.stamps + 2, 1ull);
-    }
-#endif
 }
-
-template <int BM, int BN, bool WT, int K>
-struct PrologueLoop {
-    static __device__ __forceinline__ void run(const IgemmArgs& p, float* As, float* Bs, LoadState<BM / 32, BN / 32>& st, int nsteps,
-                                               int kchunks, int wave, int lane) {
-        constexpr int STAGES = Ring<BM, BN>::stages;
-        if constexpr (K < STAGES - 1) {
-            issue_stage<BM, BN, WT>(p, As + K * (BM * BK), Bs + K * (BK * BN), st, nsteps, kchunks, K == 0, wave, lane);
-            PrologueLoop<BM, BN, WT, K + 1>::run(p, As, Bs, st, nsteps, kchunks, wave, lane);
-        }
-    }
-};
+// ... and of the fused-BatchNorm kernel: the A slot consumed now was written (transformed) during the previous step;
+// between the MFMA halves the lane transforms the NEXT step's A chunks out of their raw slot, then re-targets that raw slot
+// with the DMA of STAGES steps ahead and issues the B DMA of STAGES - 1 steps ahead.
+template <int BM, int BN, bool WT, bool F16, int AT>
+__device__ __forceinline__ void pipe_step_fused(const IgemmArgs& p, float* __restrict__ a_next, float* __restrict__ b_dst,
+                                                float* __restrict__ raw, float* __restrict__ raw2,
+                                                const float* __restrict__ a_src, const float* __restrict__ b_src,
+                                                const float* __restrict__ tab, int kp, f32x16 (&acc)[BM / 64][BN / 64],
+                                                AMeta& r, ALoad<BM / 32, ATr<AT>::two>& sa, BLoad<BN / 32>& sb,
+                                                int nsteps, int kchunks, int wave, int lane, int wm, int wn) {
+    constexpr int LPS = (BM / 32) * (ATr<AT>::two ? 2 : 1) + BN / 32;
+    wait_vmcnt<(Ring<BM, BN>::stages - 2) * LPS>();      // this step's B tile and the next step's raw A chunks have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my transformed chunks of this step are in LDS
+    __builtin_amdgcn_s_barrier();
+    Frags<BM, BN, WT> f;
+    load_frags<BM, BN, WT>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
+    XIn<BM / 32, AT> xin;
+    transform_load<BM, AT>(r, raw, raw2, sa.achunk, tab, kp, xin, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_frags<BM, BN, WT, F16, 0, BK / 16>(f, acc);
+    transform_store<BM, AT>(r, xin, a_next, wave, lane);
+    issue_a_raw<BM, AT>(p, raw, raw2, r, sa, nsteps, kchunks, false, wave, lane);
+    issue_b_dma<BN, WT>(p, b_dst, sb, nsteps, kchunks, wave, lane);
+    mfma_frags<BM, BN, WT, F16, BK / 16, BK / 8>(f, acc);
+}
 
 template <int BM, int BN, bool WT, bool F16, int K>
 struct StepLoop {
-    static __device__ __forceinline__ void run(const IgemmArgs& p, float* As, float* Bs, f32x16 (&acc)[BM / 64][BN / 64],
-                                               LoadState<BM / 32, BN / 32>& st, int base, int nsteps, int kchunks, int wave,
-                                               int lane, int wm, int wn, bool loads, bool computes) {
-        constexpr int STAGES = Ring<BM, BN>::stages;
-        if constexpr (K < STAGES) {
+    static __device__ __forceinline__ void run(const IgemmArgs& p, float* ring, f32x16 (&acc)[BM / 64][BN / 64],
+                                               ALoad<BM / 32, false>& sa, BLoad<BN / 32>& sb, int base, int nsteps, int kchunks,
+                                               int wave, int lane, int wm, int wn) {
+        using L = Lds<BM, BN, 0>;
+        if constexpr (K < L::STAGES) {
             if (base + K < nsteps) {
-                constexpr int D = (K + STAGES - 1) % STAGES;      // stage refilled while stage K is consumed
-                pipe_step<BM, BN, WT, F16>(p, As + D * (BM * BK), Bs + D * (BK * BN), As + K * (BM * BK), Bs + K * (BK * BN), acc, st,
-                                      nsteps, kchunks, wave, lane, wm, wn, loads, computes);
+                constexpr int D = (K + L::STAGES - 1) % L::STAGES;      // stage refilled while stage K is consumed
+                pipe_step<BM, BN, WT, F16>(p, ring + D * L::A_STAGE, ring + L::B_OFF + D * L::B_STAGE, ring + K * L::A_STAGE,
+                                           ring + L::B_OFF + K * L::B_STAGE, acc, sa, sb, nsteps, kchunks, wave, lane, wm, wn);
             }
-            StepLoop<BM, BN, WT, F16, K + 1>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn, loads, computes);
+            StepLoop<BM, BN, WT, F16, K + 1>::run(p, ring, acc, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
+        }
+    }
+};
+// fused: the period of (B slot, A slot, raw slot) is STAGES * (STAGES - 1) steps, all indices compile-time
+template <int BM, int BN, bool WT, bool F16, int AT, int K>
+struct FusedLoop {
+    static __device__ __forceinline__ void run(const IgemmArgs& p, float* ring, const float* tab, int kp, f32x16 (&acc)[BM / 64][BN / 64],
+                                               AMeta (&meta)[Ring<BM, BN>::stages - 1], ALoad<BM / 32, ATr<AT>::two>& sa,
+                                               BLoad<BN / 32>& sb, int base, int nsteps, int kchunks, int wave, int lane, int wm, int wn) {
+        using L = Lds<BM, BN, AT>;
+        constexpr int S = L::STAGES, PERIOD = S * (S - 1);
+        if constexpr (K < PERIOD) {
+            if (base + K < nsteps) {
+                constexpr int RS = (K + 1) % (S - 1);       // raw slot of step K + 1 (and then of step K + S)
+                pipe_step_fused<BM, BN, WT, F16, AT>(p, ring + ((K + 1) % 2) * L::A_STAGE, ring + L::B_OFF + ((K + S - 1) % S) * L::B_STAGE,
+                                                     ring + L::RAW_OFF + RS * L::A_STAGE, ring + L::RAW2_OFF + RS * L::A_STAGE,
+                                                     ring + (K % 2) * L::A_STAGE, ring + L::B_OFF + (K % S) * L::B_STAGE, tab, kp, acc,
+                                                     meta[RS], sa, sb, nsteps, kchunks, wave, lane, wm, wn);
+            }
+            FusedLoop<BM, BN, WT, F16, AT, K + 1>::run(p, ring, tab, kp, acc, meta, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
         }
     }
 };
 
-template <int BM, int BN, bool WT, bool F16 = false>
-__global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(const IgemmArgs p) {
+// ---- coefficient tables of the fused BatchNorms (one thread per channel, every block computes the same bits) ------------
+// channel k's sums over up to P3D_FOLD_MAX per-tile partials, in tile order, double accumulation.  Every load is issued
+// before the first add (indices past the end re-read the last partial and are not added): ONE memory latency, where a
+// counted loop's remainder iterations would each pay their own (measured: +7 us per launch at 13 partials).
+__device__ __forceinline__ void fold_partials(const float* part_base, int nparts, int C, int k, double& s1, double& s2) {
+    const float2* part = reinterpret_cast<const float2*>(part_base) + k;
+    float2 v[P3D_FOLD_MAX];
+#pragma unroll
+    for (int q = 0; q < P3D_FOLD_MAX; ++q) v[q] = part[(size_t)min(q, nparts - 1) * C];
+#pragma unroll
+    for (int q = 0; q < P3D_FOLD_MAX; ++q)
+        if (q < nparts) { s1 += (double)v[q].x; s2 += (double)v[q].y; }
+}
+// forward: scale / shift from the producer's per-tile (sum, sumsq): mean and variance in double (E[x^2] - mean^2 cancels),
+// the rest in float; `owner` (block 0 of the launch, when the launch is the BN's publisher) stores what the backward
+// pass needs and updates the moving statistics (tf.layers.batch_normalization, momentum 0.99)
+__device__ __forceinline__ void bn_fold_channel(const BnFold& f, int k, bool owner, float& sc, float& sh) {
+    if (!f.part) { sc = f.scale[k]; sh = f.shift[k]; return; }
+    double s1 = 0.0, s2 = 0.0;
+    fold_partials(f.part, f.nparts, f.C, k, s1, s2);
+    const double mean = s1 * f.inv_m;
+    double var = s2 * f.inv_m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, varf = (float)var;
+    const float inv = 1.0f / sqrtf(varf + f.eps);
+    sc = f.gamma[k] * inv;
+    sh = f.beta[k] - meanf * sc;
+    if (owner && f.publish) {
+        f.scale[k] = sc; f.shift[k] = sh; f.mean[k] = meanf; f.invstd[k] = inv;
+        if (f.update_moving) {      // moving -= (moving - batch) * (1 - 0.99)   (biased variance)
+            f.moving_mean[k] -= (f.moving_mean[k] - meanf) * (1.0f - 0.99f);
+            f.moving_var[k] -= (f.moving_var[k] - varf) * (1.0f - 0.99f);
+        }
+    }
+}
+// backward: dy = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat))  as  k1*g + k2*y + k3
+__device__ __forceinline__ void bn_grad_fold_channel(const BnGradFold& f, int k, bool owner, float& k1, float& k2, float& k3) {
+    if (!f.part) { k1 = f.coef[k]; k2 = f.coef[f.C + k]; k3 = f.coef[2 * f.C + k]; return; }
+    double sg = 0.0, sgx = 0.0;
+    fold_partials(f.part, f.nparts, f.C, k, sg, sgx);
+    const float inv = f.invstd[k];
+    const float c1 = (float)(sg * f.inv_m), c2 = (float)(sgx * f.inv_m);
+    k1 = f.gamma[k] * inv;
+    k2 = -k1 * inv * c2;
+    k3 = -k1 * c1 - k2 * f.mean[k];
+    if (owner && f.publish) {
+        f.coef[k] = k1; f.coef[f.C + k] = k2; f.coef[2 * f.C + k] = k3;
+        f.dgamma[k] = (float)sgx; f.dbeta[k] = (float)sg;
+    }
+}
+
+template <int AT>
+__device__ __forceinline__ void build_table(const IgemmArgs& p, float* tab, int kp, bool owner) {
+    for (int k = threadIdx.x; k < kp; k += 256) {
+        if constexpr (AT == P3D_AT_RELU1 || AT == P3D_AT_RELU2) {
+            float s = 0.f, t = 0.f;
+            if (k < p.K) bn_fold_channel(p.f1, k, owner, s, t);
+            tab[k] = s; tab[kp + k] = t;
+            if constexpr (AT == P3D_AT_RELU2) {
+                float s2 = 0.f, t2 = 0.f;
+                if (k < p.K) bn_fold_channel(p.f2, k, owner, s2, t2);
+                tab[2 * kp + k] = s2; tab[3 * kp + k] = t2;
+            }
+        } else if constexpr (AT == P3D_AT_GRAD) {
+            float k1 = 0.f, k2 = 0.f, k3 = 0.f;
+            if (k < p.K) bn_grad_fold_channel(p.gf, k, owner, k1, k2, k3);
+            tab[k] = k1; tab[kp + k] = k2; tab[2 * kp + k] = k3;
+        }
+    }
+}
+
+__device__ __forceinline__ float4 shfl_xor4(float4 v, int o) {
+    return make_float4(__shfl_xor(v.x, o), __shfl_xor(v.y, o), __shfl_xor(v.z, o), __shfl_xor(v.w, o));
+}
+
+template <int BM, int BN, bool WT, bool F16 = false, int AT = 0>
+__global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int LA = BM / 32;                 // A glds per wave per step
-    constexpr int A_STAGE = BM * BK;            // floats
-    constexpr int B_STAGE = BK * BN;
-    constexpr int STAGES = Ring<BM, BN>::stages;
+    constexpr int LA = BM / 32;                 // A chunks per lane per step (per source)
+    using L = Lds<BM, BN, AT>;
+    constexpr int STAGES = L::STAGES;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    long long* rowOut = reinterpret_cast<long long*>(smem);               // [BM]
-    float* As = reinterpret_cast<float*>(rowOut + BM);                    // ring; the epilogue tile overlays it
-    float* Bs = As + STAGES * A_STAGE;
+    int* rowIdx = reinterpret_cast<int*>(smem);                           // [BM] output row of tile row r, -1 past M
+    float* ring = reinterpret_cast<float*>(rowIdx + BM);                  // ring; the epilogue tile overlays it
+    float* tab = ring + L::FIXED;                                         // [ncoef][kp] operand-transform coefficients
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    constexpr bool LW = Loaders<BM, BN>::on;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave8 & 3;                              // piece / sub-tile index of this wave in its role
-    const bool loads = !LW || wave8 >= 4, computes = !LW || wave8 < 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
-#if defined(P3D_TUNE_STAMPS)
-    const unsigned long long kstamp0 = __builtin_readcyclecounter();
-#endif
     const long long M = (long long)p.N * p.Gd * p.Gh * p.Gw;
     const int NT = (p.Nc + BN - 1) / BN;
     const int nsplit = p.nsplit;
-    // block -> (output tile, K-slice).  xmap: consecutive blocks are the slices of one tile, so with round-robin
-    // dispatch over the 8 XCDs slice s of every tile lands on XCD s (mod 8) and the A rows / weight slabs of a slice
-    // are fetched into one L2 once instead of eight times.  Placement is a speed matter only.
-    const int tile_id = p.xmap ? (int)(blockIdx.x / nsplit) : (int)blockIdx.x;
-    const int slice = p.xmap ? (int)(blockIdx.x - (unsigned)tile_id * nsplit) : (int)blockIdx.y;
+    const int tile_id = (int)blockIdx.x, slice = (int)blockIdx.y;      // block -> (output tile, K-slice)
     const int nt = tile_id % NT;
     const int mt = tile_id / NT;
     const long long m0 = (long long)mt * BM;
     const int n0 = nt * BN;
+    const int kchunks = (p.K + BK - 1) / BK;
+    const int kp = kchunks * BK;
 
     const unsigned Mu = (unsigned)M, m0u = (unsigned)m0;      // launcher guarantees M < 2^31
-    for (int r = tid; r < BM; r += Loaders<BM, BN>::threads) {
+    for (int r = tid; r < BM; r += 256) {
         const unsigned m = m0u + r;
-        long long ro = -1;
+        int ro = -1;
         if (m < Mu) {
             const unsigned gw = m % (unsigned)p.Gw; unsigned t = m / (unsigned)p.Gw;
             const unsigned gh = t % (unsigned)p.Gh; t /= (unsigned)p.Gh;
             const unsigned gd = t % (unsigned)p.Gd; const unsigned n = t / (unsigned)p.Gd;
             const int od = gd * p.osd + p.ood, oh = gh * p.osh + p.ooh, ow = gw * p.osw + p.oow;
-            ro = ((((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.ldy;
+            ro = (((int)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
         }
-        rowOut[r] = ro;
+        rowIdx[r] = ro;
     }
-
     // ---- this block's slice of the (tap, k-chunk) steps --------------------------------------------
-    const int kchunks = (p.K + BK - 1) / BK;
     const int total_steps = p.ntaps * kchunks;
     const int per = (total_steps + nsplit - 1) / nsplit;
     const int s_begin = slice * per;
     const int s_end = min(total_steps, s_begin + per);
-#if defined(P3D_TUNE_NO_LOOP)               // tools/micro only: the fixed cost of a launch (prologue + epilogue, no K loop)
-    const int nsteps = 0;
-#else
     const int nsteps = max(s_end - s_begin, 0);
-#endif
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -403,26 +581,45 @@ __global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(cons
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-#if defined(P3D_TUNE_STAMPS)
-    const unsigned long long kstampA = __builtin_readcyclecounter();     // after the output-row table
-#endif
-    LoadState<LA, BN / 32> st;
-    if (loads) loader_init<BM, BN, WT>(p, st, m0u, Mu, n0, wave, lane, s_begin, kchunks);
-#if defined(P3D_TUNE_STAMPS)
-    const unsigned long long kstampB = __builtin_readcyclecounter();     // after the loader's index arithmetic
-    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { atomicAdd(p.stamps + 6, kstampA - kstamp0); atomicAdd(p.stamps + 7, kstampB - kstampA); }
-#endif
-    // prologue: STAGES-1 steps in flight; then step k computes from stage k % STAGES while refilling the stage
-    // that was consumed one step earlier.  All stage addresses are compile-time constants (StepLoop).
-    if (loads) PrologueLoop<BM, BN, WT, 0>::run(p, As, Bs, st, nsteps, kchunks, wave, lane);
-#if defined(P3D_TUNE_STAMPS)
-    const unsigned long long kstamp1 = __builtin_readcyclecounter();
-#endif
-    for (int base = 0; base < nsteps; base += STAGES)
-        StepLoop<BM, BN, WT, F16, 0>::run(p, As, Bs, acc, st, base, nsteps, kchunks, wave, lane, wm, wn, loads, computes);
-#if defined(P3D_TUNE_STAMPS)
-    const unsigned long long kstamp2 = __builtin_readcyclecounter();
-#endif
+    ALoad<LA, ATr<AT>::two> sa;
+    BLoad<BN / 32> sb;
+    a_init<BM, ATr<AT>::two>(p, sa, m0u, Mu, wave, lane, s_begin, kchunks);
+    b_init<BN, WT>(p, sb, n0, wave, lane, s_begin, kchunks);
+    if constexpr (AT == P3D_AT_NONE) {
+        // prologue: STAGES-1 steps in flight; then step k computes from stage k % STAGES while refilling the stage
+        // that was consumed one step earlier.  All stage addresses are compile-time constants (StepLoop).
+#pragma unroll
+        for (int k = 0; k < STAGES - 1; ++k) {
+            issue_a_dma<BM>(p, ring + k * L::A_STAGE, sa, nsteps, kchunks, k == 0, wave, lane);
+            issue_b_dma<BN, WT>(p, ring + L::B_OFF + k * L::B_STAGE, sb, nsteps, kchunks, wave, lane);
+        }
+        for (int base = 0; base < nsteps; base += STAGES)
+            StepLoop<BM, BN, WT, F16, 0>::run(p, ring, acc, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
+    } else {
+        // fused prologue, in the issue order the steady state has (pipe_step_fused's counted wait relies on it):
+        //   A(0);  [A(1), B(0)]  (3-stage ring only);  the coefficient table (its loads queue behind those);  transform A(0);
+        //   [A(STAGES-1), B(STAGES-2)]
+        AMeta meta[STAGES - 1];
+        float* raw = ring + L::RAW_OFF;
+        float* raw2 = ring + L::RAW2_OFF;
+        issue_a_raw<BM, AT>(p, raw, raw2, meta[0], sa, nsteps, kchunks, true, wave, lane);
+        if constexpr (STAGES == 3) {
+            issue_a_raw<BM, AT>(p, raw + L::A_STAGE, raw2 + L::A_STAGE, meta[1], sa, nsteps, kchunks, false, wave, lane);
+            issue_b_dma<BN, WT>(p, ring + L::B_OFF, sb, nsteps, kchunks, wave, lane);
+        }
+        build_table<AT>(p, tab, kp, tile_id == 0 && slice == 0);
+        wait_vmcnt<0>();
+        __syncthreads();                                    // table complete; the DMA above has landed
+        {
+            XIn<LA, AT> xin;
+            transform_load<BM, AT>(meta[0], raw, raw2, sa.achunk, tab, kp, xin, wave, lane);
+            transform_store<BM, AT>(meta[0], xin, ring, wave, lane);
+        }
+        issue_a_raw<BM, AT>(p, raw, raw2, meta[0], sa, nsteps, kchunks, false, wave, lane);
+        issue_b_dma<BN, WT>(p, ring + L::B_OFF + (STAGES - 2) * L::B_STAGE, sb, nsteps, kchunks, wave, lane);
+        for (int base = 0; base < nsteps; base += STAGES * (STAGES - 1))
+            FusedLoop<BM, BN, WT, F16, AT, 0>::run(p, ring, tab, kp, acc, meta, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
+    }
 
     // ---- epilogue ----------------------------------------------------------------------------------
     // Stage the tile through LDS (the ring is free once the tail DMA has landed) so that global traffic is row-wise
@@ -430,12 +627,11 @@ __global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(cons
     // and the per-channel statistics all come from the staged tile.
     constexpr int LDT = BN + 4;
     constexpr int F4R = BN / 4;
-    float* tile = As;
-    float* sred = tile + BM * LDT;                              // [4][BN][2] statistics exchange
-    int* flag = reinterpret_cast<int*>(sred + 4 * BN * 2);      // "this block reduces the slices" (same LDS array: no second object)
+    float* tile = ring;
+    float* sred = tile + BM * LDT;                              // [2][4][BN][2] statistics exchange
+    int* flag = reinterpret_cast<int*>(sred + 2 * 4 * BN * 2);  // "this block reduces the slices" (same LDS array: no second object)
     wait_vmcnt<0>();
-    __syncthreads();                                            // also orders rowOut (written above) before its readers
-    if (LW && !computes) return;                                // loader waves are done: the epilogue is the compute waves'
+    __syncthreads();                                            // also orders rowIdx (written above) before its readers
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -520,19 +716,87 @@ __global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(cons
         __syncthreads();
     }
 
+    if (p.ngate > 0) {
+        // -- gated output (input gradient through fused BatchNorm + ReLU pairs): every lane owns ONE float4 column group
+        //    (256 % F4R == 0) and walks rows, so the per-channel (sum g, sum g*xhat) accumulate in registers; lanes of a
+        //    wave that share the column group are folded by shuffles, the four waves through LDS, all in a fixed order.
+        const int c4 = (tid % F4R) * 4, col = n0 + c4;
+        const bool cok = col < p.Nc;
+        float4 sc[2], sh[2], mu[2], iv[2], s[2], sx[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            s[q] = make_float4(0.f, 0.f, 0.f, 0.f); sx[q] = s[q]; sc[q] = s[q]; sh[q] = s[q]; mu[q] = s[q]; iv[q] = s[q];
+            if (q < p.ngate && cok) {
+                sc[q] = *reinterpret_cast<const float4*>(p.gate[q].scale + col); sh[q] = *reinterpret_cast<const float4*>(p.gate[q].shift + col);
+                mu[q] = *reinterpret_cast<const float4*>(p.gate[q].mean + col); iv[q] = *reinterpret_cast<const float4*>(p.gate[q].invstd + col);
+            }
+        }
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll 2
+        for (int r = tid / F4R; r < BM; r += 256 / F4R) {
+            const int ro = rowIdx[r];
+            if (ro < 0 || !cok) continue;
+            float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
+            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+            if (p.accum) { const float4 o = *reinterpret_cast<const float4*>(p.y + (long long)ro * p.ldy + col); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (p.raw_store) *reinterpret_cast<float4*>(p.y + (long long)ro * p.ldy + col) = v;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (q >= p.ngate) break;
+                const float4 y4 = *reinterpret_cast<const float4*>(p.gate[q].y + (long long)ro * p.gate[q].ldy + col);
+                float4 g;
+                g.x = fmaf(sc[q].x, y4.x, sh[q].x) > 0.f ? v.x : 0.f; g.y = fmaf(sc[q].y, y4.y, sh[q].y) > 0.f ? v.y : 0.f;
+                g.z = fmaf(sc[q].z, y4.z, sh[q].z) > 0.f ? v.z : 0.f; g.w = fmaf(sc[q].w, y4.w, sh[q].w) > 0.f ? v.w : 0.f;
+                *reinterpret_cast<float4*>(p.gate[q].out + (long long)ro * p.gate[q].ldo + col) = g;
+                s[q].x += g.x; s[q].y += g.y; s[q].z += g.z; s[q].w += g.w;
+                sx[q].x = fmaf(g.x, (y4.x - mu[q].x) * iv[q].x, sx[q].x); sx[q].y = fmaf(g.y, (y4.y - mu[q].y) * iv[q].y, sx[q].y);
+                sx[q].z = fmaf(g.z, (y4.z - mu[q].z) * iv[q].z, sx[q].z); sx[q].w = fmaf(g.w, (y4.w - mu[q].w) * iv[q].w, sx[q].w);
+            }
+        }
+        __syncthreads();                        // everyone is done with the tile: sred may be reused
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q >= p.ngate) break;
+#pragma unroll
+            for (int o = F4R; o < 64; o <<= 1) {
+                const float4 a = shfl_xor4(s[q], o), b = shfl_xor4(sx[q], o);
+                s[q].x += a.x; s[q].y += a.y; s[q].z += a.z; s[q].w += a.w;
+                sx[q].x += b.x; sx[q].y += b.y; sx[q].z += b.z; sx[q].w += b.w;
+            }
+            if (lane < F4R) {
+                float* d = sred + ((q * 4 + wave) * BN + c4) * 2;
+                d[0] = s[q].x; d[1] = sx[q].x; d[2] = s[q].y; d[3] = sx[q].y; d[4] = s[q].z; d[5] = sx[q].z; d[6] = s[q].w; d[7] = sx[q].w;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && (n0 + tid) < p.Nc) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (q >= p.ngate) break;
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { t1 += sred[((q * 4 + w) * BN + tid) * 2]; t2 += sred[((q * 4 + w) * BN + tid) * 2 + 1]; }
+                float* dst = p.gate[q].part + ((size_t)mt * p.Nc + n0 + tid) * 2;
+                dst[0] = t1; dst[1] = t2;
+            }
+        }
+        return;
+    }
+
     // -- output rows: bias, optional accumulate, row-wise float4 stores; the stored values go back to the tile for the
     //    statistics pass --------------------------------------------------------------------------------------------
     const bool want_stats = p.statpart != nullptr;
 #pragma unroll 4
     for (int i = tid; i < BM * F4R; i += 256) {
         const int r = i / F4R, c4 = (i - r * F4R) * 4;
-        const long long ro = rowOut[r];
+        const int ro = rowIdx[r];
         const int col = n0 + c4;
         if (ro < 0 || col >= p.Nc) continue;
         float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
         if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         if (want_stats) *reinterpret_cast<float4*>(tile + r * LDT + c4) = v;
-        float* dst = p.y + ro + col;
+        float* dst = p.y + (long long)ro * p.ldy + col;
         if (p.accum) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *reinterpret_cast<float4*>(dst) = v;
     }
@@ -544,7 +808,7 @@ __global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(cons
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
         for (int r = rg * RPG; r < (rg + 1) * RPG; ++r)
-            if (rowOut[r] >= 0) { const float v = tile[r * LDT + col]; s1 += v; s2 = fmaf(v, v, s2); }
+            if (rowIdx[r] >= 0) { const float v = tile[r * LDT + col]; s1 += v; s2 = fmaf(v, v, s2); }
         sred[(rg * BN + col) * 2] = s1; sred[(rg * BN + col) * 2 + 1] = s2;
         __syncthreads();
         if (tid < BN && (n0 + tid) < p.Nc) {
@@ -555,20 +819,25 @@ __global__ __launch_bounds__((Loaders<BM, BN>::threads)) void igemm2_kernel(cons
             dst[0] = t1; dst[1] = t2;
         }
     }
-#if defined(P3D_TUNE_STAMPS)
-    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long kstamp3 = __builtin_readcyclecounter();
-        atomicAdd(p.stamps + 3, kstamp1 - kstamp0); atomicAdd(p.stamps + 4, kstamp3 - kstamp2); atomicAdd(p.stamps + 5, 1ull);
-    }
-#endif
 }
 
-template <int BM, int BN>
-constexpr size_t smem_bytes() {
-    const size_t ring = (size_t)Ring<BM, BN>::stages * (BM * BK + BK * BN) * 4;
-    const size_t tile = (size_t)BM * (BN + 4) * 4 + 4 * BN * 2 * 4 + 16;   // staged tile + statistics exchange + reducer flag
-    return BM * 8 + (ring > tile ? ring : tile);
+constexpr int MAX_TABLE_FLOATS = 4 * 2048;        // coefficient table: up to 4 coefficients x 2048 reduction channels
+
+template <int BM, int BN, int AT>
+constexpr size_t smem_fixed_bytes() { return (size_t)BM * 4 + (size_t)Lds<BM, BN, AT>::FIXED * 4; }
+
+template <int BM, int BN, bool WT, bool F16, int AT>
+hipError_t launch_variant(const IgemmArgs& a, dim3 grid, hipStream_t s) {
+    constexpr size_t fixed = smem_fixed_bytes<BM, BN, AT>();
+    static std::once_flag once;
+    std::call_once(once, [] {
+        hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, WT, F16, AT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(fixed + (AT ? MAX_TABLE_FLOATS * 4 : 0)));
+    });
+    const size_t kp = (size_t)((a.K + BK - 1) / BK) * BK;
+    const size_t sm = fixed + (size_t)ATr<AT>::ncoef * kp * 4;
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, WT, F16, AT>), grid, dim3(256), sm, s, a);
+    return hipGetLastError();
 }
 
 template <int BM, int BN>
@@ -577,30 +846,25 @@ hipError_t launch_t(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) 
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const long long tiles = ((M + BM - 1) / BM) * ((a.Nc + BN - 1) / BN);
     const int splits = pl.splits < 1 ? 1 : pl.splits;
-    a.nsplit = splits; a.xmap = (splits > 1 && pl.xmap) ? 1 : 0;
+    a.nsplit = splits;
     a.slab = nullptr; a.cnt = nullptr;
     if (splits > 1) {
         const hipError_t e = p3d_stream_scratch(s, (size_t)tiles * splits * BM * BN, (size_t)tiles, &a.slab, &a.cnt);
         if (e != hipSuccess) return e;
     }
-    const dim3 grid = a.xmap ? dim3((unsigned)(tiles * splits)) : dim3((unsigned)tiles, (unsigned)splits);
-    constexpr size_t sm = smem_bytes<BM, BN>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipFuncSetAttribute((const void*)igemm2_kernel<BM, BN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        attr_done = true;
+    const dim3 grid((unsigned)tiles, (unsigned)splits);
+    // forward convs ([K][Nc] weights) take the relu transforms, input gradients ([Nc][K] weights) the gradient transform
+    if (a.wT) {
+        if (a.at_mode == P3D_AT_GRAD) return a.f16 ? launch_variant<BM, BN, true, true, P3D_AT_GRAD>(a, grid, s) : launch_variant<BM, BN, true, false, P3D_AT_GRAD>(a, grid, s);
+        if (a.at_mode != P3D_AT_NONE) return hipErrorInvalidValue;
+        return a.f16 ? launch_variant<BM, BN, true, true, 0>(a, grid, s) : launch_variant<BM, BN, true, false, 0>(a, grid, s);
     }
-    if (a.f16) {
-        if (a.wT) hipLaunchKernelGGL((igemm2_kernel<BM, BN, true, true>), grid, dim3(Loaders<BM, BN>::threads), sm, s, a);
-        else      hipLaunchKernelGGL((igemm2_kernel<BM, BN, false, true>), grid, dim3(Loaders<BM, BN>::threads), sm, s, a);
-        return hipGetLastError();
+    switch (a.at_mode) {
+        case P3D_AT_NONE: return a.f16 ? launch_variant<BM, BN, false, true, 0>(a, grid, s) : launch_variant<BM, BN, false, false, 0>(a, grid, s);
+        case P3D_AT_RELU1: return a.f16 ? launch_variant<BM, BN, false, true, P3D_AT_RELU1>(a, grid, s) : launch_variant<BM, BN, false, false, P3D_AT_RELU1>(a, grid, s);
+        case P3D_AT_RELU2: return a.f16 ? launch_variant<BM, BN, false, true, P3D_AT_RELU2>(a, grid, s) : launch_variant<BM, BN, false, false, P3D_AT_RELU2>(a, grid, s);
+        default: return hipErrorInvalidValue;
     }
-    if (a.wT) hipLaunchKernelGGL((igemm2_kernel<BM, BN, true>), grid, dim3(Loaders<BM, BN>::threads), sm, s, a);
-    else      hipLaunchKernelGGL((igemm2_kernel<BM, BN, false>), grid, dim3(Loaders<BM, BN>::threads), sm, s, a);
-    return hipGetLastError();
 }
 
 // ---- per-stream scratch (partial tiles + arrival counters) -----------------------------------------------------
@@ -647,28 +911,15 @@ namespace {
 // ---- plan: tile and K-slices per launch ------------------------------------------------------------------------
 // Big layers take the biggest tile that still yields enough blocks (least LDS traffic per FLOP).  Layers with few
 // output tiles cut K into slices: wall time is about one block's latency until blocks exceed the 256 CUs, so the
-// slice count aims at 0.75-1x the CU count, never 2x (cdna_hip_programming.md, "Projection GEMM at M = 256", item 1),
-// and is a divisor pattern of 8 so that xmap can give each XCD one slice.  Every plan is numerically valid; plans
-// differ only in speed and in the (fixed, per-plan) summation order of the K-slices.
+// slice count aims at 0.75-1x the CU count, never 2x (cdna_hip_programming.md, "Projection GEMM at M = 256", item 1).
+// Every plan is numerically valid; plans differ only in speed and in the (fixed, per-plan) summation order of the K-slices.
 const char* plan_name(int bm, int bn) {
     return bm == 128 ? (bn == 128 ? "igemm2_kernel<128,128>" : "igemm2_kernel<128,64>") : "igemm2_kernel<64,64>";
 }
 
-struct PlanOverride { int tile = -1, splits = 0, xmap = -1; };
+struct PlanOverride { int tile = -1, splits = 0; };
 PlanOverride g_override;
-std::once_flag g_override_once;
 std::mutex g_plan_mutex;
-
-void read_override_env() {
-    // Tuning sweeps only (tools/): force the tile, the K-slice count or the block mapping.  Read once; a forced value
-    // that a shape cannot take is ignored for that shape.
-    if (const char* e = getenv("P3D_TILE")) g_override.tile = atoi(e);
-    if (const char* e = getenv("P3D_SPLITS")) g_override.splits = atoi(e);
-    if (const char* e = getenv("P3D_XMAP")) g_override.xmap = atoi(e);
-    if (g_override.tile >= 0 || g_override.splits > 0 || g_override.xmap >= 0)
-        fprintf(stderr, "[p3d] WARNING: igemm2 plan override in effect (P3D_TILE=%d P3D_SPLITS=%d P3D_XMAP=%d): tuning only\n",
-                g_override.tile, g_override.splits, g_override.xmap);
-}
 
 P3dIgemmPlan heuristic_plan(const IgemmArgs& a) {
     P3dIgemmPlan pl;
@@ -680,7 +931,7 @@ P3dIgemmPlan heuristic_plan(const IgemmArgs& a) {
     if (a.Nc > 64 && tiles(128, 128) >= want) { pl.bm = 128; pl.bn = 128; }
     else if (tiles(128, 64) >= want || (a.Nc <= 64 && tiles(128, 64) >= 128)) { pl.bm = 128; pl.bn = 64; }
     else { pl.bm = 64; pl.bn = 64; }
-    pl.splits = 1; pl.xmap = 0;
+    pl.splits = 1;
     const long long t = tiles(pl.bm, pl.bn);
     if (pl.bm == 64 && pl.bn == 64 && t < 150 && steps >= 8) {
         // Measured on MI355X (tools/micro/conv_chain.hip, M = 784 rows, cold weights): a 64x64 step costs ~0.78 us while
@@ -703,15 +954,13 @@ P3dIgemmPlan heuristic_plan(const IgemmArgs& a) {
 
 void p3d_tune_begin(hipStream_t) {}
 void p3d_tune_end() {}
-void p3d_igemm2_override(int tile, int splits, int xmap) {      // tools/micro only
-    std::call_once(g_override_once, read_override_env);
+void p3d_igemm2_override(int tile, int splits) {      // tests / tools only
     std::lock_guard<std::mutex> g(g_plan_mutex);
-    g_override.tile = tile; g_override.splits = splits; g_override.xmap = xmap;
+    g_override.tile = tile; g_override.splits = splits;
 }
 
 // Tile / K-slice choice for one launch.
 P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int) {
-    std::call_once(g_override_once, read_override_env);
     P3dIgemmPlan pl = heuristic_plan(a);
     PlanOverride ov;
     { std::lock_guard<std::mutex> g(g_plan_mutex); ov = g_override; }
@@ -719,28 +968,37 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int) {
     if (ov.tile == 0) { pl.bm = 64; pl.bn = 64; }
     else if (ov.tile == 1) { pl.bm = 128; pl.bn = 64; }
     else if (ov.tile == 2 && a.Nc > 64) { pl.bm = 128; pl.bn = 128; }
-    if (ov.splits >= 1 && ov.splits <= steps) { pl.splits = ov.splits; if (pl.splits == 1) pl.xmap = 0; }
-    if (ov.xmap >= 0) pl.xmap = (ov.xmap && pl.splits > 1) ? 1 : 0;
+    if (ov.splits >= 1 && ov.splits <= steps) pl.splits = ov.splits;
     pl.name = plan_name(pl.bm, pl.bn);
     return pl;
 }
 
-namespace { hipError_t launch_plan(const IgemmArgs& a, const P3dIgemmPlan& pl, hipStream_t s); }
-hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& pl, hipStream_t s) { return launch_plan(a, pl, s); }
-
-namespace {
-hipError_t launch_plan(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) {
+hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) {
     IgemmArgs a = a0;
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     if (M <= 0 || a.Nc <= 0) return hipSuccess;
     if (M >= (1ll << 31) || (long long)a.N * a.Di * a.Hi * a.Wi >= (1ll << 31)) return hipErrorInvalidValue;
+    if ((long long)a.N * a.Do * a.Ho * a.Wo >= (1ll << 31)) return hipErrorInvalidValue;                    // int row index
     if (a.Gd * a.isd >= 1024 || a.Gh * a.ish >= 1024 || a.Gw * a.isw >= 1024) return hipErrorInvalidValue;   // packed coords
     if (a.ntaps > P3D_MAX_TAPS) return hipErrorInvalidValue;
     if ((a.K & 3) || (a.ldx & 3) || !a.zeros) return hipErrorInvalidValue;
     if ((a.Nc & 3) || (a.ldy & 3)) return hipErrorInvalidValue;
     if (pl.splits > 1 && pl.splits > a.ntaps * ((a.K + BK - 1) / BK)) return hipErrorInvalidValue;
+    if (a.at_mode != P3D_AT_NONE) {
+        const long long kp = (long long)((a.K + BK - 1) / BK) * BK;
+        if (kp * 4 > MAX_TABLE_FLOATS) return hipErrorInvalidValue;
+        if ((a.at_mode == P3D_AT_RELU2 || a.at_mode == P3D_AT_GRAD) && (!a.x2 || (a.ldx2 & 3))) return hipErrorInvalidValue;
+    }
+    if (a.at_mode == P3D_AT_RELU1 || a.at_mode == P3D_AT_RELU2) {
+        if (a.f1.part && (a.f1.nparts < 1 || a.f1.nparts > P3D_FOLD_MAX)) return hipErrorInvalidValue;
+        if (a.at_mode == P3D_AT_RELU2 && a.f2.part && (a.f2.nparts < 1 || a.f2.nparts > P3D_FOLD_MAX)) return hipErrorInvalidValue;
+    }
+    if (a.at_mode == P3D_AT_GRAD && a.gf.part && (a.gf.nparts < 1 || a.gf.nparts > P3D_FOLD_MAX)) return hipErrorInvalidValue;
+    if (a.ngate < 0 || a.ngate > 2) return hipErrorInvalidValue;
+    for (int q = 0; q < a.ngate; ++q)
+        if (!a.gate[q].y || !a.gate[q].out || !a.gate[q].part || (a.gate[q].ldy & 3) || (a.gate[q].ldo & 3)) return hipErrorInvalidValue;
+    if (a.ngate && a.statpart) return hipErrorInvalidValue;
     if (pl.bm == 128 && pl.bn == 128) return launch_t<128, 128>(a, pl, s);
     if (pl.bm == 128 && pl.bn == 64) return launch_t<128, 64>(a, pl, s);
     return launch_t<64, 64>(a, pl, s);
 }
-}  // namespace

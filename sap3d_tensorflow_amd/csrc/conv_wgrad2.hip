@@ -15,6 +15,12 @@
 // partial tile to a scratch slab and takes an arrival ticket; the block with the last ticket adds the
 // slabs in cut order and updates dW (and the bias gradient) with plain read-modify-writes.  No float
 // atomics anywhere: two runs give bit-identical gradients.
+//
+// FUSED BatchNorm (round 3, template parameter FUSED; see p3d_kernels.h "BatchNorm fused into the convolutions' operand
+// paths"): a problem may read its gathered operand as relu(s1*x + t1) [+ relu(s2*x2 + t2)] and its dense operand as
+// k1*dy + k2*dy2 + k3 -- the normalised activations and BatchNorm's input gradients are never stored.  The per-channel
+// coefficients sit in registers (a lane's fragment channel is fixed for the whole kernel) and are applied between
+// ds_read and MFMA; padded / out-of-range rows of a relu-transformed operand read a NaN page (relu(NaN) = 0).
 #include "p3d_kernels.h"
 #include <algorithm>
 #include <cstdio>
@@ -35,13 +41,6 @@ constexpr int BKM = 32;
 #endif
 template <int BM>
 struct WRing { static constexpr int stages = (BM >= 128) ? 2 : 3; };   // 128x128: 64 KB -> two blocks per CU
-// Loader waves for the 64x64 tile (conv_igemm2.hip, "Loader waves"): waves 0-3 read fragments and issue MFMAs, waves 4-7
-// wait for and issue the LDS-DMA, one of each per SIMD; the loaders leave after the last step.
-#ifndef P3D_LW64
-#define P3D_LW64 0
-#endif
-template <int BM>
-struct WLoaders { static constexpr bool on = (BM == 64 && P3D_LW64); static constexpr int threads = on ? 512 : 256; };
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -63,16 +62,21 @@ struct WProb {
     int tile0;           // first (tile) slot of this problem in the scratch slabs / counters
     int ntaps;
     int pair;            // K <= 32: a 64-row tile holds TWO taps (rows 0-31 tap 2i, rows 32-63 tap 2i+1) -- the stem's K = 28
+    // fused BatchNorm (WgradArgs): operand transforms and their per-channel coefficients
+    int xt, dyt;
+    int ldx2, ldy2;
+    const float* x2; const float* xs1; const float* xt1; const float* xs2; const float* xt2;
+    const float* dy2; const float* dcoef;
     signed char tap[P3D_MAX_TAPS][4];      // dd, dh, dw, weight slab
 };
 struct WGroup {
     int nprob;
-    const float* zeros;
+    const float* zeros; const float* nans;
     float* slab; unsigned* cnt;
     int kstride;         // slab index of (slot, cut) = slot * kstride + cut
     WProb p[P3D_WGRAD_GROUP];
 };
-static_assert(sizeof(WGroup) <= 3800, "kernel arguments must stay under the 4 KB kernarg segment");
+static_assert(sizeof(WGroup) <= 3900, "kernel arguments must stay under the 4 KB kernarg segment");
 
 // Per-lane loader state in registers: the lattice coordinates of the rows this lane fetches, advanced
 // by 32 positions per step with small-integer reciprocal carries (no per-step division).
@@ -83,6 +87,7 @@ struct WState {
     int kc[LA];                     // channel offset of this lane's 16-byte chunk
     const float* bptr[LB];          // dY row pointer (+ chunk), advanced by 32 rows per step
     unsigned bm[LB];
+    int bnc[LB];                    // dY column of this lane's chunk
     bool bok[LB];
     unsigned rGw, rGh, rGd;         // ceil(2^16 / extent)
 };
@@ -106,25 +111,29 @@ __device__ __forceinline__ void wloader_init(const WProb& p, WState<BM / 32, BN 
     for (int i = 0; i < LB; ++i) {
         const unsigned m = ms + (i * 4 + wave) * B_RPP + lane / B_LPR;
         const int nc = n0 + (lane % B_LPR) * 4;
-        st.bm[i] = m; st.bok[i] = nc < p.Nc;
+        st.bm[i] = m; st.bnc[i] = nc; st.bok[i] = nc < p.Nc;
         st.bptr[i] = p.dy + (long long)m * p.ldy + nc;
     }
 }
 
-// Always LA + LB loads (rows past the slice end, padded rows and channel tails read the zero page).
-template <int BM, int BN>
-__device__ __forceinline__ void issue_stage(const WProb& p, const float* zeros, int tdd, int tdh, int tdw, float* __restrict__ a_dst,
-                                            float* __restrict__ b_dst, WState<BM / 32, BN / 32>& st, unsigned me, int wave,
-                                            int lane) {
+// Always the same number of loads per step for a block (rows past the slice end, padded rows and channel tails read the
+// pad page): LA + LB, plus LA when the gathered operand has a second source, plus LB when the dense one has.
+template <int BM, int BN, bool FUSED>
+__device__ __forceinline__ void issue_stage(const WProb& p, const float* zeros, const float* apad, int tdd, int tdh, int tdw,
+                                            float* __restrict__ a_dst, float* __restrict__ a2_dst, float* __restrict__ b_dst,
+                                            float* __restrict__ b2_dst, WState<BM / 32, BN / 32>& st, unsigned me, bool two_x,
+                                            bool two_dy, int wave, int lane) {
     constexpr int LA = BM / 32, LB = BN / 32;
     const float* zp = zeros + 4 * (lane & 7);
+    const float* ap = apad + 4 * (lane & 7);        // NaN page under a relu transform, else zeros
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int id = st.gd[i] * p.isd + tdd, ih = st.gh[i] * p.ish + tdh, iw = st.gw[i] * p.isw + tdw;
         const bool ok = st.m[i] < me && st.kc[i] < p.K && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
                         (unsigned)iw < (unsigned)p.Wi;
-        const float* src = ok ? p.x + ((((long long)st.n[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw) * p.ldx + st.kc[i] : zp;
-        glds16(src, a_dst + (i * 4 + wave) * 256);
+        const long long row = (((long long)st.n[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw;
+        glds16(ok ? p.x + row * p.ldx + st.kc[i] : ap, a_dst + (i * 4 + wave) * 256);
+        if (FUSED && two_x) glds16(ok ? p.x2 + row * p.ldx2 + st.kc[i] : ap, a2_dst + (i * 4 + wave) * 256);
         // advance 32 positions
         st.m[i] += BKM;
         int gw = st.gw[i] + BKM;
@@ -142,20 +151,33 @@ __device__ __forceinline__ void issue_stage(const WProb& p, const float* zeros, 
     for (int i = 0; i < LB; ++i) {
         const bool ok = st.bm[i] < me && st.bok[i];
         glds16(ok ? st.bptr[i] : zp, b_dst + (i * 4 + wave) * 256);
+        if (FUSED && two_dy) glds16(ok ? p.dy2 + (long long)st.bm[i] * p.ldy2 + st.bnc[i] : zp, b2_dst + (i * 4 + wave) * 256);
         st.bm[i] += BKM;
         st.bptr[i] += (long long)BKM * p.ldy;
     }
 }
 
+// Per-lane coefficients of the operand transforms: a lane's fragment channel (A) and column (B) never change.
+template <int BM, int BN>
+struct WCoef {
+    float s1[BM / 64], t1[BM / 64], s2[BM / 64], t2[BM / 64];      // x:  relu(s1*x + t1) + relu(s2*x2 + t2)
+    float k1[BN / 64], k2[BN / 64], k3[BN / 64];                    // dy: k1*dy + k2*dy2 + k3
+};
+
 // All fragment reads of a stage are issued before its first MFMA (one exposed LDS latency per step instead of one per
 // pair of MFMAs); the stage is then consumed in two halves so that the next refill's address arithmetic and DMA issue
-// run while the first half's MFMAs execute (same arrangement as conv_igemm2.hip's pipe_step).
-template <int BM, int BN>
-struct WFrags { float a[BKM / 2][BM / 64]; float b[BKM / 2][BN / 64]; };
+// run while the first half's MFMAs execute (same arrangement as conv_igemm2.hip's pipe_step).  The operand transforms are
+// applied pair by pair inside the MFMA loop: a pair's few VALU operations issue in the shadow of the previous MFMA.
+template <int BM, int BN, bool FUSED>
+struct WFrags {
+    float a[BKM / 2][BM / 64]; float b[BKM / 2][BN / 64];
+    float a2[FUSED ? BKM / 2 : 1][BM / 64]; float b2[FUSED ? BKM / 2 : 1][BN / 64];
+};
 
-template <int BM, int BN>
-__device__ __forceinline__ void load_wfrags(const float* __restrict__ a_st, const float* __restrict__ b_st, WFrags<BM, BN>& f,
-                                            int wm, int wn, int h, int l31) {
+template <int BM, int BN, bool FUSED>
+__device__ __forceinline__ void load_wfrags(const float* __restrict__ a_st, const float* __restrict__ a2_st,
+                                            const float* __restrict__ b_st, const float* __restrict__ b2_st,
+                                            WFrags<BM, BN, FUSED>& f, bool two_x, bool two_dy, int wm, int wn, int h, int l31) {
     constexpr int TM = BM / 64, TN = BN / 64;
 #pragma unroll
     for (int k2 = 0; k2 < BKM / 2; ++k2) {
@@ -164,78 +186,104 @@ __device__ __forceinline__ void load_wfrags(const float* __restrict__ a_st, cons
 #pragma unroll
         for (int j = 0; j < TN; ++j) f.b[k2][j] = b_st[(2 * k2 + h) * BN + wn * (BN / 2) + j * 32 + l31];
     }
+    if constexpr (FUSED) {
+        if (two_x) {
+#pragma unroll
+            for (int k2 = 0; k2 < BKM / 2; ++k2)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) f.a2[k2][i] = a2_st[(2 * k2 + h) * BM + wm * (BM / 2) + i * 32 + l31];
+        }
+        if (two_dy) {
+#pragma unroll
+            for (int k2 = 0; k2 < BKM / 2; ++k2)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) f.b2[k2][j] = b2_st[(2 * k2 + h) * BN + wn * (BN / 2) + j * 32 + l31];
+        }
+    }
 }
-template <int BM, int BN, int K0, int K1>
-__device__ __forceinline__ void mfma_wfrags(const WFrags<BM, BN>& f, f32x16 (&acc)[BM / 64][BN / 64]) {
+// nvalid: positions of this step inside the block's range (32 except in the last step) -- the bias sums skip the others
+template <int BM, int BN, bool FUSED, int K0, int K1>
+__device__ __forceinline__ void mfma_wfrags(WFrags<BM, BN, FUSED>& f, const WCoef<BM, BN>& cf, int xt, int dyt,
+                                            f32x16 (&acc)[BM / 64][BN / 64], float (&bsum)[BN / 64], bool do_bias, int nvalid, int h) {
     constexpr int TM = BM / 64, TN = BN / 64;
 #pragma unroll
-    for (int k2 = K0 / 2; k2 < K1 / 2; ++k2)
+    for (int k2 = K0 / 2; k2 < K1 / 2; ++k2) {
+        if constexpr (FUSED) {
+            if (xt) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float r = fmaxf(fmaf(cf.s1[i], f.a[k2][i], cf.t1[i]), 0.f);
+                    if (xt == 2) r += fmaxf(fmaf(cf.s2[i], f.a2[k2][i], cf.t2[i]), 0.f);
+                    f.a[k2][i] = r;
+                }
+            }
+            if (dyt) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) f.b[k2][j] = fmaf(cf.k1[j], f.b[k2][j], fmaf(cf.k2[j], f.b2[k2][j], cf.k3[j]));
+            }
+        }
+        if (do_bias) {
+            const bool in = (2 * k2 + h) < nvalid;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bsum[j] += in ? f.b[k2][j] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[k2][i], f.b[k2][j], acc[i][j], 0, 0, 0);
-}
-template <int BN>
-__device__ __forceinline__ void bias_rows(const float* __restrict__ b_st, float& bsum, bool do_bias) {
-    if (do_bias && threadIdx.x < BN) {
-#pragma unroll 8
-        for (int k = 0; k < BKM; ++k) bsum += b_st[k * BN + threadIdx.x];
     }
 }
 
-template <int BM, int BN>
-__device__ __forceinline__ void pipe_step(const WProb& p, const float* zeros, int tdd, int tdh, int tdw, float* __restrict__ a_dst,
-                                          float* __restrict__ b_dst, const float* __restrict__ a_src,
-                                          const float* __restrict__ b_src, f32x16 (&acc)[BM / 64][BN / 64], float& bsum,
-                                          bool do_bias, WState<BM / 32, BN / 32>& st, unsigned me, int wave, int lane, int wm,
-                                          int wn, bool loads) {
-    constexpr int LPS = BM / 32 + BN / 32;
-    constexpr bool LW = WLoaders<BM>::on;
-    if (!LW || loads) wait_vmcnt<(WRing<BM>::stages - 2) * LPS>();
+// operand views of one ring stage
+struct WStage { float* a; float* a2; float* b; float* b2; };
+
+template <int BM, int BN, bool FUSED>
+__device__ __forceinline__ void pipe_step(const WProb& p, const float* zeros, const float* apad, int tdd, int tdh, int tdw,
+                                          const WStage dst, const WStage src, f32x16 (&acc)[BM / 64][BN / 64],
+                                          const WCoef<BM, BN>& cf, float (&bsum)[BN / 64], bool do_bias, int nvalid,
+                                          WState<BM / 32, BN / 32>& st, unsigned me, bool two_x, bool two_dy, int wave, int lane,
+                                          int wm, int wn) {
+    constexpr int LA = BM / 32, LB = BN / 32;
+    if constexpr (WRing<BM>::stages == 2) {
+        wait_vmcnt<0>();
+    } else if constexpr (!FUSED) {
+        wait_vmcnt<LA + LB>();
+    } else {
+        // the loads of one step: LA + LB, + LA / + LB for the second sources (block-uniform)
+        if (two_x) { if (two_dy) wait_vmcnt<2 * LA + 2 * LB>(); else wait_vmcnt<2 * LA + LB>(); }
+        else { if (two_dy) wait_vmcnt<LA + 2 * LB>(); else wait_vmcnt<LA + LB>(); }
+    }
     __builtin_amdgcn_s_barrier();
-    if constexpr (LW) {
-        if (loads) {
-            issue_stage<BM, BN>(p, zeros, tdd, tdh, tdw, a_dst, b_dst, st, me, wave, lane);
-        } else {
-            WFrags<BM, BN> f;
-            load_wfrags<BM, BN>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_wfrags<BM, BN, 0, BKM>(f, acc);
-            bias_rows<BN>(b_src, bsum, do_bias);
-        }
-        return;
-    }
-    WFrags<BM, BN> f;
-    load_wfrags<BM, BN>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
+    WFrags<BM, BN, FUSED> f;
+    load_wfrags<BM, BN, FUSED>(src.a, src.a2, src.b, src.b2, f, two_x, two_dy, wm, wn, lane >> 5, lane & 31);
     __builtin_amdgcn_sched_barrier(0);      // keep every read above the MFMAs (hipcc otherwise sinks them back, pair by pair)
-    mfma_wfrags<BM, BN, 0, BKM / 2>(f, acc);
-    issue_stage<BM, BN>(p, zeros, tdd, tdh, tdw, a_dst, b_dst, st, me, wave, lane);
-    mfma_wfrags<BM, BN, BKM / 2, BKM>(f, acc);
-    bias_rows<BN>(b_src, bsum, do_bias);
+    const int xt = FUSED ? p.xt : 0, dyt = FUSED ? p.dyt : 0;
+    mfma_wfrags<BM, BN, FUSED, 0, BKM / 2>(f, cf, xt, dyt, acc, bsum, do_bias, nvalid, lane >> 5);
+    issue_stage<BM, BN, FUSED>(p, zeros, apad, tdd, tdh, tdw, dst.a, dst.a2, dst.b, dst.b2, st, me, two_x, two_dy, wave, lane);
+    mfma_wfrags<BM, BN, FUSED, BKM / 2, BKM>(f, cf, xt, dyt, acc, bsum, do_bias, nvalid, lane >> 5);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool FUSED>
 constexpr size_t wsmem_bytes() {
-    const size_t ring = (size_t)WRing<BM>::stages * BKM * (BM + BN) * 4;
+    const size_t ring = (size_t)WRing<BM>::stages * BKM * (BM + BN) * 4 * (FUSED ? 2 : 1);
     const size_t tile = (size_t)BM * (BN + 4) * 4 + BN * 4 + 16;      // staged tile + bias sums + reducer flag
     return ring > tile ? ring : tile;
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const WGroup g) {
+template <int BM, int BN, bool FUSED>
+__global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_STAGE = BKM * BM, B_STAGE = BKM * BN;
     constexpr int STAGES = WRing<BM>::stages;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);
     float* Bs = As + STAGES * A_STAGE;
+    float* A2s = Bs + STAGES * B_STAGE;                    // second sources (FUSED only)
+    float* B2s = A2s + STAGES * A_STAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    constexpr bool LW = WLoaders<BM>::on;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave8 & 3;
-    const bool loads = !LW || wave8 >= 4, computes = !LW || wave8 < 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
@@ -254,7 +302,11 @@ __global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const W
         p.Gd = src.Gd; p.Gh = src.Gh; p.Gw = src.Gw; p.isd = src.isd; p.ish = src.ish; p.isw = src.isw;
         p.ldy = src.ldy; p.Nc = src.Nc; p.ksplit = src.ksplit; p.blk0 = src.blk0; p.tile0 = src.tile0; p.ntaps = src.ntaps;
         p.pair = src.pair;
+        p.xt = FUSED ? src.xt : 0; p.dyt = FUSED ? src.dyt : 0; p.ldx2 = src.ldx2; p.ldy2 = src.ldy2;
+        p.x2 = src.x2; p.xs1 = src.xs1; p.xt1 = src.xt1; p.xs2 = src.xs2; p.xt2 = src.xt2; p.dy2 = src.dy2; p.dcoef = src.dcoef;
     }
+    const bool two_x = FUSED && p.xt == 2, two_dy = FUSED && p.dyt != 0;
+    const float* apad = (FUSED && p.xt) ? g.nans : g.zeros;
 
     const long long M = (long long)p.N * p.Gd * p.Gh * p.Gw;
     const int KT = p.pair ? 1 : (p.K + BM - 1) / BM, NT = (p.Nc + BN - 1) / BN;
@@ -292,30 +344,57 @@ __global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const W
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const bool do_bias = p.dbias != nullptr && ti == 0 && kt == 0;
-    float bsum = 0.f;
+    float bsum[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bsum[j] = 0.f;
+
+    WCoef<BM, BN> cf;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { cf.s1[i] = 0.f; cf.t1[i] = 0.f; cf.s2[i] = 0.f; cf.t2[i] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { cf.k1[j] = 0.f; cf.k2[j] = 0.f; cf.k3[j] = 0.f; }
+    if constexpr (FUSED) {
+        if (p.xt) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ch = k0 + wm * (BM / 2) + i * 32 + l31;
+                if (ch < p.K) {
+                    cf.s1[i] = p.xs1[ch]; cf.t1[i] = p.xt1[ch];
+                    if (p.xt == 2) { cf.s2[i] = p.xs2[ch]; cf.t2[i] = p.xt2[ch]; }
+                }
+            }
+        }
+        if (p.dyt) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+                if (col < p.Nc) { cf.k1[j] = p.dcoef[col]; cf.k2[j] = p.dcoef[p.Nc + col]; cf.k3[j] = p.dcoef[2 * p.Nc + col]; }
+            }
+        }
+    }
 
     WState<BM / 32, BN / 32> st;
-    if (loads) wloader_init<BM, BN>(p, st, (unsigned)ms, k0, n0, wave, lane);
+    wloader_init<BM, BN>(p, st, (unsigned)ms, k0, n0, wave, lane);
     const unsigned meu = (unsigned)me;
+    int left = (int)(me - ms);                               // positions not yet consumed
     if (STAGES == 3) {
-        float* A0 = As; float* A1 = As + A_STAGE; float* A2 = As + 2 * A_STAGE;
-        float* B0 = Bs; float* B1 = Bs + B_STAGE; float* B2 = Bs + 2 * B_STAGE;
-        if (loads) {
-            issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, st, meu, wave, lane);
-            issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, st, meu, wave, lane);
-        }
+        const WStage S0{As, A2s, Bs, B2s}, S1{As + A_STAGE, A2s + A_STAGE, Bs + B_STAGE, B2s + B_STAGE},
+                     S2{As + 2 * A_STAGE, A2s + 2 * A_STAGE, Bs + 2 * B_STAGE, B2s + 2 * B_STAGE};
+        issue_stage<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S0.a, S0.a2, S0.b, S0.b2, st, meu, two_x, two_dy, wave, lane);
+        issue_stage<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S1.a, S1.a2, S1.b, S1.b2, st, meu, two_x, two_dy, wave, lane);
         for (int base = 0; base < nsteps; base += 3) {
-            pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A2, B2, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn, loads);
-            if (base + 1 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn, loads);
-            if (base + 2 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, A2, B2, acc, bsum, do_bias, st, meu, wave, lane, wm, wn, loads);
+            pipe_step<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S2, S0, acc, cf, bsum, do_bias, left, st, meu, two_x, two_dy, wave, lane, wm, wn);
+            left -= BKM;
+            if (base + 1 < nsteps) { pipe_step<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S0, S1, acc, cf, bsum, do_bias, left, st, meu, two_x, two_dy, wave, lane, wm, wn); left -= BKM; }
+            if (base + 2 < nsteps) { pipe_step<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S1, S2, acc, cf, bsum, do_bias, left, st, meu, two_x, two_dy, wave, lane, wm, wn); left -= BKM; }
         }
     } else {
-        float* A0 = As; float* A1 = As + A_STAGE;
-        float* B0 = Bs; float* B1 = Bs + B_STAGE;
-        if (loads) issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, st, meu, wave, lane);
+        const WStage S0{As, A2s, Bs, B2s}, S1{As + A_STAGE, A2s + A_STAGE, Bs + B_STAGE, B2s + B_STAGE};
+        issue_stage<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S0.a, S0.a2, S0.b, S0.b2, st, meu, two_x, two_dy, wave, lane);
         for (int base = 0; base < nsteps; base += 2) {
-            pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn, loads);
-            if (base + 1 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn, loads);
+            pipe_step<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S1, S0, acc, cf, bsum, do_bias, left, st, meu, two_x, two_dy, wave, lane, wm, wn);
+            left -= BKM;
+            if (base + 1 < nsteps) { pipe_step<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S0, S1, acc, cf, bsum, do_bias, left, st, meu, two_x, two_dy, wave, lane, wm, wn); left -= BKM; }
         }
     }
 
@@ -326,7 +405,6 @@ __global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const W
     int* flag = reinterpret_cast<int*>(bias_lds + BN);
     wait_vmcnt<0>();
     __syncthreads();
-    if (LW && !computes) return;                                 // loader waves are done
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -336,7 +414,13 @@ __global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const W
                 const int r = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 tile[r * LDT + wn * (BN / 2) + j * 32 + l31] = acc[i][j][e];
             }
-    if (tid < BN) bias_lds[tid] = bsum;
+    if (do_bias && wm == 0) {      // column sums of dY: the two position parities (lane halves) of the waves that hold these columns
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float t = bsum[j] + __shfl_xor(bsum[j], 32);
+            if (h == 0) bias_lds[wn * (BN / 2) + j * 32 + l31] = t;
+        }
+    }
     __syncthreads();
 
     if (p.ksplit > 1) {
@@ -420,20 +504,42 @@ __global__ __launch_bounds__((WLoaders<BM>::threads)) void wgrad2_kernel(const W
 }
 
 // LDS request of a launch = residency limiter (see launch_group_t): bytes per block of a (tm x tn) tile.
-size_t lds_need(int tm, int tn) {
-    if (tm == 128 && tn == 128) return wsmem_bytes<128, 128>();
-    if (tm == 128) return wsmem_bytes<128, 64>();
-    if (tn == 128) return wsmem_bytes<64, 128>();
-    return wsmem_bytes<64, 64>();
+size_t lds_need(int tm, int tn, bool fused) {
+    if (fused) {
+        if (tm == 128 && tn == 128) return wsmem_bytes<128, 128, true>();
+        if (tm == 128) return wsmem_bytes<128, 64, true>();
+        if (tn == 128) return wsmem_bytes<64, 128, true>();
+        return wsmem_bytes<64, 64, true>();
+    }
+    if (tm == 128 && tn == 128) return wsmem_bytes<128, 128, false>();
+    if (tm == 128) return wsmem_bytes<128, 64, false>();
+    if (tn == 128) return wsmem_bytes<64, 128, false>();
+    return wsmem_bytes<64, 64, false>();
 }
-size_t lds_request(int tm, int tn) {
-    const size_t need = lds_need(tm, tn);
+// tuning knobs: compile-time defaults; a -DP3D_TUNING build (tools/*.sh via P3D_EXTRA_HIPCC_FLAGS) reads them from the environment once
+struct WTune { long lds_kb = P3D_WGRAD64_LDS_KB; int slots = 0; bool no_rect = false; long long polite_rows = P3D_WGRAD_POLITE_ROWS; };
+const WTune& wtune() {
+    static const WTune t = [] {
+        WTune w;
+#if defined(P3D_TUNING)
+        if (const char* e = getenv("P3D_WGRAD_LDS_KB")) { const long v = atol(e); if (v > 0 && v <= 160) w.lds_kb = v; }
+        if (const char* e = getenv("P3D_WGRAD_SLOTS")) w.slots = atoi(e);
+        if (getenv("P3D_WGRAD_NO_RECT")) w.no_rect = true;
+        if (const char* e = getenv("P3D_WGRAD_POLITE_ROWS")) w.polite_rows = atoll(e);
+#endif
+        return w;
+    }();
+    return t;
+}
+size_t lds_request(int tm, int tn, bool fused) {
+    const size_t need = lds_need(tm, tn, fused);
     if (tm != 64 || tn != 64) return need;
-    size_t want = (size_t)P3D_WGRAD64_LDS_KB * 1024;
-    static const long forced = getenv("P3D_WGRAD_LDS_KB") ? atol(getenv("P3D_WGRAD_LDS_KB")) : 0;
-    if (forced > 0 && forced <= 160) want = (size_t)forced * 1024;
+    const size_t want = (size_t)wtune().lds_kb * 1024;
     return want < need ? need : want;
 }
+
+// test hook (p3d_wgrad2_force_tile): force the tile of single-problem launches where the problem allows it
+int g_force_tm = 0, g_force_tn = 0;
 
 struct WPlan { int tm, tn; long long tiles; int ks; double cost; };
 long long tiles_of(const WgradArgs& a, int tm, int tn) {
@@ -454,7 +560,7 @@ WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
         w.tiles = tiles_of(a, TM_, TN_);
         // the model keeps 3 (2) slots per CU whatever the residency limit: with one resident block per CU the launch then
         // runs in ~3 short rounds, and short blocks are what lets main-stream blocks in (17.47 vs 17.78 ms / step)
-        static const int per_cu = getenv("P3D_WGRAD_SLOTS") ? atoi(getenv("P3D_WGRAD_SLOTS")) : 0;
+        const int per_cu = wtune().slots;
         const int area = TM_ * TN_;
         const long long slots = 256 * (per_cu > 0 ? per_cu : (area > 4096 ? 2 : 3));
         const double step_time = area == 16384 ? 3.2 : (area == 8192 ? 1.75 : 1.0), overhead = 8.0;
@@ -477,18 +583,14 @@ WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
     // cut count still comes from the model above: a cost model of its own that counted work per CU picked fewer, longer
     // blocks and lost 0.2-3.6 ms per step on every workload although each filter gradient alone was faster.
     if (a.pair) return best_for(64, 64);
-    const bool busy = other_tiles == 0 && M > P3D_WGRAD_POLITE_ROWS && a.Nc >= 128 && getenv("P3D_WGRAD_NO_RECT") == nullptr &&
-                      getenv("P3D_WGRAD_TILE") == nullptr;
+    const bool forced = g_force_tm != 0;
+    const bool busy = other_tiles == 0 && M > P3D_WGRAD_POLITE_ROWS && a.Nc >= 128 && !wtune().no_rect && !forced;
     if (busy) return best_for(64, 128);
     WPlan best = best_for(64, 64);
     if (other_tiles == 0) {
-        // tests and sweeps force a tile shape (read per call, unlike the tuning switches): P3D_WGRAD_TILE=64x128 | 128x64 | 128x128 | 64x64
-        if (const char* f = getenv("P3D_WGRAD_TILE")) {
-            int fm = 0, fn = 0;
-            if (sscanf(f, "%dx%d", &fm, &fn) == 2 && (fm == 64 || fm == 128) && (fn == 64 || fn == 128)) {
-                if ((fm == 64 || a.K >= 128) && (fn == 64 || a.Nc >= 128)) return best_for(fm, fn);
-                return best;
-            }
+        if (forced) {
+            if ((g_force_tm == 64 || a.K >= 128) && (g_force_tn == 64 || a.Nc >= 128)) return best_for(g_force_tm, g_force_tn);
+            return best;
         }
         if (a.K >= 128 && a.Nc >= 128) { const WPlan w = best_for(128, 128); if (w.cost <= best.cost) best = w; }
     }
@@ -501,6 +603,9 @@ bool wgrad_ok(const WgradArgs& a) {
     if (a.ntaps > P3D_MAX_TAPS || !a.zeros) return false;
     if ((a.K & 3) || (a.ldx & 3) || (a.Nc & 3) || (a.ldy & 3)) return false;
     if (a.pair && a.K > 32) return false;
+    if (a.xt < 0 || a.xt > 2 || (a.xt && (a.pair || !a.nans || !a.xs1 || !a.xt1))) return false;
+    if (a.xt == 2 && (!a.x2 || !a.xs2 || !a.xt2 || (a.ldx2 & 3))) return false;
+    if (a.dyt && (!a.dy2 || !a.dcoef || (a.ldy2 & 3) || a.pair)) return false;
     for (int t = 0; t < a.ntaps; ++t)
         if (a.taps[t].dd < -128 || a.taps[t].dd > 127 || a.taps[t].dh < -128 || a.taps[t].dh > 127 || a.taps[t].dw < -128 ||
             a.taps[t].dw > 127 || a.taps[t].widx < 0 || a.taps[t].widx > 127)
@@ -513,13 +618,15 @@ void fill_prob(WProb& p, const WgradArgs& a) {
     p.N = a.N; p.Di = a.Di; p.Hi = a.Hi; p.Wi = a.Wi; p.ldx = a.ldx; p.K = a.K;
     p.Gd = a.Gd; p.Gh = a.Gh; p.Gw = a.Gw; p.isd = a.isd; p.ish = a.ish; p.isw = a.isw;
     p.ldy = a.ldy; p.Nc = a.Nc; p.ntaps = a.ntaps; p.pair = a.pair;
+    p.xt = a.xt; p.dyt = a.dyt ? 1 : 0; p.ldx2 = a.ldx2; p.ldy2 = a.ldy2;
+    p.x2 = a.x2; p.xs1 = a.xs1; p.xt1 = a.xt1; p.xs2 = a.xs2; p.xt2 = a.xt2; p.dy2 = a.dy2; p.dcoef = a.dcoef;
     for (int t = 0; t < a.ntaps; ++t) {
         p.tap[t][0] = (signed char)a.taps[t].dd; p.tap[t][1] = (signed char)a.taps[t].dh;
         p.tap[t][2] = (signed char)a.taps[t].dw; p.tap[t][3] = (signed char)a.taps[t].widx;
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool FUSED>
 hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slots, bool greedy, bool polite, hipStream_t s) {
     // LDS request = residency limiter.  The filter gradients share the chip with the main stream's chain of small launches,
     // whose blocks (igemm2 64x64: 48.5 KB of LDS) must find room on every CU while a filter-gradient launch is resident:
@@ -527,9 +634,9 @@ hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slot
     // retire.  82 KB per 64x64 block = one block per CU: 17.97 -> 17.78 ms / step on one box, 17.93 -> 17.47 on another
     // (55 KB, two per CU: 17.68).  The plan below still cuts for three slots per CU -- short blocks retire often.
     static const size_t sm = [] {
-        const size_t want = lds_request(BM, BN);
-        hipFuncSetAttribute((const void*)wgrad2_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)std::max(want, lds_request(64, 64)));
+        const size_t want = lds_request(BM, BN, FUSED);
+        hipFuncSetAttribute((const void*)wgrad2_kernel<BM, BN, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)std::max(want, lds_request(64, 64, FUSED)));
         return want;
     }();
     g.slab = nullptr; g.cnt = nullptr;
@@ -540,9 +647,9 @@ hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slot
     // greedy: nothing else runs beside this launch (the stem's, last of the backward pass) -- full residency
     // not greedy: a 64x64 tile takes its polite request (one block per CU); a larger tile at least as much when the launch
     // is marked polite (it was parked to run beside the encoder's chain)
-    size_t lds = greedy ? wsmem_bytes<BM, BN>() : sm;
-    if (polite && lds < lds_request(64, 64)) lds = lds_request(64, 64);
-    hipLaunchKernelGGL((wgrad2_kernel<BM, BN>), dim3((unsigned)blocks), dim3(WLoaders<BM>::threads), lds, s, g);
+    size_t lds = greedy ? wsmem_bytes<BM, BN, FUSED>() : sm;
+    if (polite && lds < lds_request(64, 64, FUSED)) lds = lds_request(64, 64, FUSED);
+    hipLaunchKernelGGL((wgrad2_kernel<BM, BN, FUSED>), dim3((unsigned)blocks), dim3(256), lds, s, g);
     return hipGetLastError();
 }
 
@@ -552,6 +659,10 @@ const char* p3d_wgrad2_variant(const WgradArgs& a) {
     const WPlan w = plan(a);
     return w.tm == 128 ? (w.tn == 128 ? "wgrad2_kernel<128,128>" : "wgrad2_kernel<128,64>")
                        : (w.tn == 128 ? "wgrad2_kernel<64,128>" : "wgrad2_kernel<64,64>");
+}
+void p3d_wgrad2_force_tile(int tm, int tn) {
+    const bool ok = (tm == 64 || tm == 128) && (tn == 64 || tn == 128);
+    g_force_tm = ok ? tm : 0; g_force_tn = ok ? tn : 0;
 }
 
 // One launch for up to P3D_WGRAD_GROUP problems.  A single problem may take the 128x128 tile; groups use 64x64.
@@ -570,6 +681,8 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
     memset(&g, 0, sizeof(g));
     g.nprob = (int)live.size();
     g.zeros = live[0]->zeros;
+    bool fused = false;
+    for (auto* a : live) { if (a->xt || a->dyt) fused = true; if (a->nans) g.nans = a->nans; }
     const WPlan solo = live.size() == 1 ? plan(*live[0]) : WPlan{64, 64, 0, 1, 0.0};
     const int tm = solo.tm, tn = solo.tn;
     long long tiles64_all = 0;
@@ -602,12 +715,17 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
         polite |= a->polite != 0; force |= a->greedy != 0;
         max_m = std::max(max_m, (long long)a->N * a->Gd * a->Gh * a->Gw);
     }
-    static const long long polite_rows = getenv("P3D_WGRAD_POLITE_ROWS") ? atoll(getenv("P3D_WGRAD_POLITE_ROWS")) : P3D_WGRAD_POLITE_ROWS;   // tuning
-    const bool greedy = !polite && (force || max_m > polite_rows);
-    if (tm == 128) return tn == 128 ? launch_group_t<128, 128>(g, blocks, slabs, tile0, greedy, polite, s)
-                                    : launch_group_t<128, 64>(g, blocks, slabs, tile0, greedy, polite, s);
-    return tn == 128 ? launch_group_t<64, 128>(g, blocks, slabs, tile0, greedy, polite, s)
-                     : launch_group_t<64, 64>(g, blocks, slabs, tile0, greedy, polite, s);
+    const bool greedy = !polite && (force || max_m > wtune().polite_rows);
+    if (fused) {
+        if (tm == 128) return tn == 128 ? launch_group_t<128, 128, true>(g, blocks, slabs, tile0, greedy, polite, s)
+                                        : launch_group_t<128, 64, true>(g, blocks, slabs, tile0, greedy, polite, s);
+        return tn == 128 ? launch_group_t<64, 128, true>(g, blocks, slabs, tile0, greedy, polite, s)
+                         : launch_group_t<64, 64, true>(g, blocks, slabs, tile0, greedy, polite, s);
+    }
+    if (tm == 128) return tn == 128 ? launch_group_t<128, 128, false>(g, blocks, slabs, tile0, greedy, polite, s)
+                                    : launch_group_t<128, 64, false>(g, blocks, slabs, tile0, greedy, polite, s);
+    return tn == 128 ? launch_group_t<64, 128, false>(g, blocks, slabs, tile0, greedy, polite, s)
+                     : launch_group_t<64, 64, false>(g, blocks, slabs, tile0, greedy, polite, s);
 }
 
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s) { return p3d_launch_wgrad2_group(&a, 1, s); }

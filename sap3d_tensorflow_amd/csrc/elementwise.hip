@@ -312,6 +312,32 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int t
     }
 }
 
+// Fused BatchNorm backward (conv_igemm2.hip, bn_grad_fold_channel) for MANY partials: 16 lanes per channel fold the gating
+// launch's per-tile (sum g, sum g*xhat) in a fixed order and publish k1 / k2 / k3 and the parameter gradients.
+__global__ __launch_bounds__(256) void bn_grad_finalize_kernel(BnGradFold f) {
+    const int r = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = c < f.C;
+    double sg = 0.0, sgx = 0.0;
+    if (ok) {
+        const float2* part = reinterpret_cast<const float2*>(f.part) + c;
+#pragma unroll 4
+        for (int q = r; q < f.nparts; q += 16) {
+            const float2 v = part[(size_t)q * f.C];
+            sg += (double)v.x; sgx += (double)v.y;
+        }
+    }
+    sg = fold16(sg); sgx = fold16(sgx);
+    if (!ok || r) return;
+    const float inv = f.invstd[c];
+    const float c1 = (float)(sg * f.inv_m), c2 = (float)(sgx * f.inv_m);
+    const float k1 = f.gamma[c] * inv;
+    const float k2 = -k1 * inv * c2;
+    const float k3 = -k1 * c1 - k2 * f.mean[c];
+    f.coef[c] = k1; f.coef[f.C + c] = k2; f.coef[2 * f.C + c] = k3;
+    f.dgamma[c] = (float)sgx; f.dbeta[c] = (float)sg;
+}
+
 __device__ __forceinline__ void ldcoef(const float* coef, int c, float4& c1, float4& c2) {
     const float4 lo = ld4(coef + 2 * c), hi = ld4(coef + 2 * c + 4);     // (s,x,s,x) (s,x,s,x)
     c1 = make_float4(lo.x, lo.z, hi.x, hi.z);
@@ -661,6 +687,12 @@ hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
 
 hipError_t p3d_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 15) / 16), dim3(256), 0, s, a, (a.mode == 2 || a.mode == 3) ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t p3d_bn_grad_finalize(const BnGradFold& f, hipStream_t s) {
+    if (!f.part || f.nparts <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3((f.C + 15) / 16), dim3(256), 0, s, f);
     return hipGetLastError();
 }
 

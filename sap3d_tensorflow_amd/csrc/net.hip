@@ -66,6 +66,8 @@ struct Act {
     std::vector<Act*> views;
     char* last_flag = nullptr;      // accumulate-flag of the most recently registered consumer
     bool whole_consumed = false;    // a consumer of the whole buffer (all views) is registered
+    // BatchNorm fusion: a normalised tensor that the fused forward never stores; reading it (p3d_get_activation) runs this
+    std::function<void(hipStream_t)> materialize;
     int64_t rows() const { return (int64_t)N * D * H * W; }
 };
 
@@ -79,6 +81,11 @@ struct BN {
     float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;
     bool follows_flag = false;      // obeys the `training` placeholder (stem / decoder); else always batch stats
     bool used_batch = true;         // what the last forward used
+    // BatchNorm fusion (p3d_kernels.h): backward partials (sum g, sum g*xhat) per output tile of the gating launch, and the
+    // published k1 / k2 / k3 of dy = k1*g + k2*y + k3
+    bool fusable = false;
+    int64_t gpart_off = -1; int gpart_cap = 0; int gnparts = 0;
+    float* coef = nullptr;
 };
 
 // Per-launch HIP-event timing (p3d_profile_step): one record per kernel launch, on the launch stream.
@@ -120,6 +127,7 @@ struct Ctx {
     const float* lr_dev = nullptr;
     bool update_moving = false;
     bool per_sample = false;          // batch-statistics BNs normalise every clip by its own statistics (p3d_predict_windows)
+    bool fuse = false;                // BatchNorm fused into the neighbouring convs' operand paths (set by run_forward / run_backward)
     hipStream_t s = nullptr;
     Prof* prof = nullptr;
     hipStream_t side = nullptr;       // weight gradients run here, off the backward critical path
@@ -150,6 +158,7 @@ void launch(const Ctx& c, const char* kernel, double flops, double bytes, F&& f)
 }
 
 const float* g_zero_page = nullptr;      // 1 KiB of zeros (device), set by p3d_create / op entry points
+const float* g_nan_page = nullptr;       // 1 KiB of quiet NaNs: padded rows of relu-transformed operands (conv_igemm2.hip)
 
 void igemm_work(const IgemmArgs& a, double& flops, double& bytes) {
     const double M = (double)a.N * a.Gd * a.Gh * a.Gw;
@@ -163,10 +172,19 @@ void launch_igemm(const Ctx& c, const IgemmArgs& a0, int allow_split = 0) {
     IgemmArgs a = a0;
     double fl, by;
     igemm_work(a, fl, by);
-    a.zeros = g_zero_page;
+    a.zeros = g_zero_page; a.nans = g_nan_page;
     const P3dIgemmPlan pl = p3d_igemm2_plan(a, allow_split);
     const char* name = pl.name;
     if (a.f16) name = pl.bm == 128 ? (pl.bn == 128 ? "igemm2_kernel<128,128,f16>" : "igemm2_kernel<128,64,f16>") : "igemm2_kernel<64,64,f16>";
+    else if (a.at_mode || a.ngate) {      // fused-BatchNorm variants get their own rows in the per-kernel tables
+        static const char* const tiles[3] = {"64,64", "128,64", "128,128"};
+        static const char* const ats[4] = {"", ",relu1", ",relu2", ",bngrad"};
+        static std::map<int, std::string> names;
+        const int key = (pl.bm == 128 ? (pl.bn == 128 ? 2 : 1) : 0) * 8 + a.at_mode * 2 + (a.ngate ? 1 : 0);
+        std::string& nm = names[key];
+        if (nm.empty()) nm = std::string("igemm2_kernel<") + tiles[key / 8] + ats[a.at_mode] + (a.ngate ? ",gate" : "") + ">";
+        name = nm.c_str();
+    }
     launch(c, name, fl, by, [&]() { return p3d_launch_igemm2(a, pl, c.s); });
 }
 
@@ -251,7 +269,7 @@ void launch_wgrad(const Ctx& c, const WgradArgs& a0) {
     const double side = (double)a.N * a.Di * a.Hi * a.Wi;
     const double fl = 2.0 * M * a.ntaps * (double)a.K * a.Nc;
     const double by = 4.0 * (std::min(M * a.ntaps, side) * a.K + M * a.Nc + (double)a.ntaps * a.K * a.Nc);
-    a.zeros = g_zero_page;
+    a.zeros = g_zero_page; a.nans = g_nan_page;
     launch(c, p3d_wgrad2_variant(a), fl, by, [&]() { return p3d_launch_wgrad2(a, c.s); });
 }
 
@@ -467,9 +485,11 @@ void ensure_zero_page() {
     // one page per process; igemm2 reads it for padded rows and channel tails
     if (g_zero_page) return;
     float* p = nullptr;
-    HIPCHECK(hipMalloc((void**)&p, 1024));
+    HIPCHECK(hipMalloc((void**)&p, 2048));
     HIPCHECK(hipMemset(p, 0, 1024));
-    g_zero_page = p;
+    std::vector<uint32_t> nan(256, 0x7fc00000u);
+    HIPCHECK(hipMemcpy(p + 256, nan.data(), 1024, hipMemcpyHostToDevice));
+    g_zero_page = p; g_nan_page = p + 256;
 }
 }  // namespace
 
@@ -668,7 +688,7 @@ struct p3d_handle {
     void queue_wgrad(const Ctx& c, const WgradArgs& a0) {
         if (c.dry) return;
         WgradArgs a = a0;
-        a.zeros = g_zero_page;
+        a.zeros = g_zero_page; a.nans = g_nan_page;
         const double M = (double)a.N * a.Gd * a.Gh * a.Gw;
         const double side = (double)a.N * a.Di * a.Hi * a.Wi;
         PendingWgrad pw;
@@ -696,7 +716,9 @@ struct p3d_handle {
         std::vector<WgradArgs> probs;
         double fl = 0, by = 0;
         for (auto& q : wq) { probs.push_back(q.a); fl += q.flops; by += q.bytes; }
-        const char* name = probs.size() == 1 ? p3d_wgrad2_variant(probs[0]) : "wgrad2_kernel<64,64>(grouped)";
+        bool any_fused = false;
+        for (auto& pr : probs) any_fused |= pr.xt != 0 || pr.dyt != 0;
+        const char* name = probs.size() == 1 ? p3d_wgrad2_variant(probs[0]) : (any_fused ? "wgrad2_kernel<64,64,fused>(grouped)" : "wgrad2_kernel<64,64>(grouped)");
         if (c.defer) {            // parked: it will run beside the encoder's chain of small launches -- low residency (conv_wgrad2.hip)
             for (auto& pr : probs) pr.polite = 1;
             parked_flops += fl;
@@ -707,13 +729,101 @@ struct p3d_handle {
         wq.clear();
     }
 
+    // ---- BatchNorm fused into the bottleneck convs' operand paths (p3d_kernels.h, conv_igemm2.hip) ---------------
+    // The bn -> relu pairs INSIDE a bottleneck (p3d.py:56-81,88-97: after conv1, convS, convT) are not passes of their own
+    // when fuse_bn is on: the consumer conv normalises its A fragments on the fly, the input-gradient launches gate and
+    // reduce, the next input-gradient / filter-gradient launch applies BatchNorm's backward on its operand path.  The
+    // unfused ops stay in the graph (per-sample inference statistics, p3d_set_bn_fusion(h, 0), parity tests of one
+    // path against the other) and run instead when Ctx::fuse is off.
+    bool fuse_bn = true;
+    bool last_forward_fused = false;
+    // Only bottlenecks whose inner tensors have at most this many rows are built fusable: there a BatchNorm pass is a
+    // latency-bound launch of its own (stage 3 at 8 clips of 16x112x112: 784 rows), while on big tensors the passes stream at
+    // HBM speed and the convs are throughput-bound, so per-step operand work costs more than the passes it removes
+    // (measured per stage).  P3D_FUSE_MAX_ROWS (read once, at p3d_create) overrides it for A/B runs.
+    int64_t fuse_max_rows = 2048;
+    static constexpr int FOLD_MAX = P3D_FOLD_MAX;      // up to this many partials per channel a consumer folds in its own prologue; beyond, a finalize launch
+    struct FuseSrc { Act* y = nullptr; BN* bn = nullptr; int pub = 0; };   // pub: 0 read the published scale / shift, 1 fold the partials and publish, 2 fold only
+    struct ConvFuse {
+        int at = 0;                          // P3D_AT_RELU1 / P3D_AT_RELU2 on the conv's input
+        FuseSrc src[2];
+        int ngate = 0; FuseSrc gate[2];      // input-gradient epilogue: gated result -> gate.y->g, partial sums -> gate.bn
+        Act* raw = nullptr; char* raw_flag = nullptr;     // ... and the raw result there (added to it when *raw_flag)
+        bool accum_in = false;               // the raw gradient another consumer left in x->g is added before gating
+        BN* out_bn = nullptr;                // the conv's output feeds a fused BatchNorm: dy = k1*g + k2*y + k3 on the operand paths
+        bool any() const { return at != 0 || out_bn != nullptr; }
+    };
+    void make_fusable(BN* bn, int64_t rows) {
+        if (bn->fusable) return;
+        bn->fusable = true;
+        reserve_stat_parts(bn, rows);
+        bn->gpart_cap = (int)(rows / 64 + 8);
+        bn->gpart_off = statpart_count;
+        statpart_count += (int64_t)bn->gpart_cap * bn->C * 2;
+        const int64_t o = bnbuf_count; bnbuf_count += 3 * (int64_t)bn->C;
+        late_bind.push_back([this, bn, o]() { bn->coef = bnbuf + o; });
+    }
+    // forward: many partials -> one finalize launch that every consumer then reads (must precede a fork to the side stream)
+    std::map<BN*, bool> fwd_finalized, grad_finalized;      // per pass: the published values are complete
+    void fused_prefinalize(const Ctx& c, const ConvFuse& cf, int64_t rows) {
+        if (c.dry) return;
+        for (int q = 0; q < (cf.at == P3D_AT_RELU2 ? 2 : 1); ++q) {
+            BN* bn = cf.src[q].bn;
+            if (cf.src[q].pub != 1) continue;
+            fwd_finalized[bn] = false;
+            bn->used_batch = true;
+            if (bn->nparts > FOLD_MAX) {
+                launch(c, "bn_finalize_kernel", 0, 64.0 * bn->C, [&]() { return p3d_bn_finalize(bn_params(bn), (long)rows, 1, c.update_moving ? 1 : 0, 1e-3f, c.s); });
+                fwd_finalized[bn] = true;
+            }
+        }
+    }
+    BnFold bn_fold(const FuseSrc& s, int64_t rows, const Ctx& c) {
+        BN* bn = s.bn;
+        BnFold f;
+        memset(&f, 0, sizeof(f));
+        f.gamma = bn->gamma->p; f.beta = bn->beta->p; f.C = bn->C;
+        f.scale = bn->scale; f.shift = bn->shift; f.mean = bn->mean; f.invstd = bn->invstd;
+        f.moving_mean = bn->mm->p; f.moving_var = bn->mv->p;
+        f.inv_m = 1.0 / (double)rows; f.eps = 1e-3f;
+        const bool fold = s.pub != 0 && !fwd_finalized[bn];
+        if (fold) { f.part = statpart_arena + bn->part_off; f.nparts = bn->nparts; }
+        f.publish = (fold && s.pub == 1) ? 1 : 0;
+        f.update_moving = c.update_moving ? 1 : 0;
+        return f;
+    }
+    BnGradFold bn_grad_fold(BN* bn, int64_t rows, bool publish) {
+        BnGradFold f;
+        memset(&f, 0, sizeof(f));
+        f.gamma = bn->gamma->p; f.mean = bn->mean; f.invstd = bn->invstd; f.C = bn->C;
+        f.coef = bn->coef; f.dgamma = bn->gamma->g; f.dbeta = bn->beta->g;
+        f.inv_m = 1.0 / (double)rows;
+        const bool fold = !grad_finalized[bn];
+        if (fold) { f.part = statpart_arena + bn->gpart_off; f.nparts = bn->gnparts; }
+        f.publish = (fold && publish) ? 1 : 0;
+        return f;
+    }
+    BnGate bn_gate(const FuseSrc& s) {
+        BnGate g;
+        memset(&g, 0, sizeof(g));
+        g.y = s.y->p; g.ldy = s.y->ld;
+        g.scale = s.bn->scale; g.shift = s.bn->shift; g.mean = s.bn->mean; g.invstd = s.bn->invstd;
+        g.out = s.y->g; g.ldo = s.y->ld;
+        g.part = statpart_arena + s.bn->gpart_off;
+        return g;
+    }
+
     // ---- graph ops ---------------------------------------------------------------------------
     // tf.nn.conv3d / tf.layers.conv3d: SAME conv, optional bias, optional BN-statistics epilogue.
     Act* conv(const std::string& opname, Act* x, Param* w, Param* bias, const int k[3], const int s[3], int Cout, BN* bn,
-              const std::string& out_name, bool stem = false, bool bn_has_dropout = false, bool fwd_on_side = false) {
+              const std::string& out_name, bool stem = false, bool bn_has_dropout = false, bool fwd_on_side = false,
+              const ConvFuse* fuse = nullptr) {
         const ConvGeo g = make_geo(x->D, x->H, x->W, k, s);
         Act* y = new_act(out_name, x->N, g.O[0], g.O[1], g.O[2], Cout);
         if (bn && stats_target(bn, y->rows(), Cout, bn_has_dropout)) reserve_stat_parts(bn, y->rows());
+        const ConvFuse cf = fuse ? *fuse : ConvFuse();
+        if (cf.out_bn) { if (cf.out_bn != bn) throw P3dError("fused output BatchNorm must be the conv's own"); make_fusable(bn, y->rows()); }
+        if (cf.ngate && (s[0] != 1 || s[1] != 1 || s[2] != 1)) throw P3dError("gated input gradients need a stride-1 conv");
         char* xflag = x->g ? consume(x) : nullptr;
         const int Cin = x->C;
         const int ntap = k[0] * k[1] * k[2];
@@ -724,6 +834,8 @@ struct p3d_handle {
         op.bflops = op.flops * (x->g ? 2 : 1);
         op.bbytes = op.bytes * (x->g ? 2 : 1);
         op.owns = {w}; if (bias) op.owns.push_back(bias);
+        // a fused BatchNorm's parameter gradients come out of this conv's input-gradient launch (bn_grad_fold_channel)
+        if (cf.out_bn) { op.owns.push_back(cf.out_bn->gamma); op.owns.push_back(cf.out_bn->beta); }
         hipEvent_t fork_ev = new_fork_event();
         if (stem) {
             // firstconv1 (p3d.py:172) on the pipelined kernels: 4-channel, W-padded copy of the clip, kw*4 contiguous
@@ -756,10 +868,20 @@ struct p3d_handle {
             return y;
         }
         auto fwd_body = [=](const Ctx& c) {
-            std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
+            const bool fz = c.fuse && cf.at != 0;
+            // fused: the A operand is the raw output of the conv before the BatchNorm (src[0].y), normalised on the fly
+            const Act* xs = fz ? cf.src[0].y : x;
+            std::vector<IgemmArgs> v{igemm_conv_forward(g, x->N, xs->p, xs->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr,
                                                         0, stem)};
+            if (fz) {
+                IgemmArgs& a = v[0];
+                a.at_mode = cf.at;
+                a.f1 = bn_fold(cf.src[0], cf.src[0].y->rows(), c);
+                if (cf.at == P3D_AT_RELU2) { a.x2 = cf.src[1].y->p; a.ldx2 = cf.src[1].y->ld; a.f2 = bn_fold(cf.src[1], cf.src[1].y->rows(), c); }
+            }
             if (ntap == 1 && !stem && pointwise_f16) v[0].f16 = 1;
-            BN* sbn = bn ? stats_target(bn, y->rows(), Cout, bn_has_dropout) : nullptr;
+            // a fused BatchNorm behind this conv always needs the tile partials (the one-launch small-tensor BN does not)
+            BN* sbn = bn ? ((c.fuse && cf.out_bn) ? bn : stats_target(bn, y->rows(), Cout, bn_has_dropout)) : nullptr;
             StatSink sink; if (sbn) sink = bn_sink(sbn);
             run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? &sink : nullptr);
         };
@@ -767,18 +889,74 @@ struct p3d_handle {
         // stream next to it and the caller joins the streams (join_side) before their outputs are combined
         hipEvent_t fork_fwd = fwd_on_side ? new_fork_event() : nullptr;
         op.fwd = [=](const Ctx& c) {
+            if (c.fuse && cf.at) fused_prefinalize(c, cf, cf.src[0].y->rows());      // on the main stream, ahead of a fork
             if (fwd_on_side && c.side && !c.dry) on_side_stream(c, fork_fwd, fwd_body);
             else fwd_body(c);
         };
         op.bwd = [=](const Ctx& c) {
-            queue_wgrad(c, wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr, stem));
-            if (xflag) {
-                const int accum = *xflag;
-                auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, w->p, nullptr, accum,
-                                               /*include_empty=*/!accum);
-                if (ntap == 1 && !stem && pointwise_f16) for (auto& a : v) a.f16 = 1;
-                run_igemm_group(c, v, x->g, x->ld, x->rows(), Cin, accum != 0, nullptr);
+            if (!(c.fuse && cf.any())) {
+                queue_wgrad(c, wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr, stem));
+                if (xflag) {
+                    const int accum = *xflag;
+                    auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, w->p, nullptr, accum,
+                                                   /*include_empty=*/!accum);
+                    if (ntap == 1 && !stem && pointwise_f16) for (auto& a : v) a.f16 = 1;
+                    run_igemm_group(c, v, x->g, x->ld, x->rows(), Cin, accum != 0, nullptr);
+                }
+                return;
             }
+            // ---- fused BatchNorm: y->g holds the GATED gradient of relu(bn(y)) (written by the consumer's input-gradient
+            //      launch), BatchNorm's own backward happens on the operand paths below
+            const bool fin = cf.at != 0;
+            WgradArgs wa = wgrad_conv(g, x->N, (fin ? cf.src[0].y : x)->p, (fin ? cf.src[0].y : x)->ld, Cin, y->g, y->ld, Cout, w->g,
+                                      bias ? bias->g : nullptr, stem);
+            if (fin) {
+                wa.xt = cf.at == P3D_AT_RELU2 ? 2 : 1;
+                wa.xs1 = cf.src[0].bn->scale; wa.xt1 = cf.src[0].bn->shift;
+                if (wa.xt == 2) { wa.x2 = cf.src[1].y->p; wa.ldx2 = cf.src[1].y->ld; wa.xs2 = cf.src[1].bn->scale; wa.xt2 = cf.src[1].bn->shift; }
+            }
+            if (cf.out_bn) { wa.dyt = 1; wa.dy2 = y->p; wa.ldy2 = y->ld; wa.dcoef = cf.out_bn->coef; }
+            if (!xflag) throw P3dError("a conv with a fused BatchNorm needs an input gradient launch (it publishes the coefficients)");
+            if (cf.out_bn && !c.dry) {
+                grad_finalized[cf.out_bn] = false;
+                if (cf.out_bn->gnparts > FOLD_MAX) {
+                    const BnGradFold gf = bn_grad_fold(cf.out_bn, y->rows(), true);
+                    launch(c, "bn_grad_finalize_kernel", 0, 64.0 * cf.out_bn->C, [&]() { return p3d_bn_grad_finalize(gf, c.s); });
+                    grad_finalized[cf.out_bn] = true;
+                }
+            }
+            // where the input gradient goes: plain inputs and ungated launches write / add to x->g; gated launches send the
+            // gated result to the gate's own buffers and use x->g (or cf.raw) for raw partial results only
+            float* py = x->g; int pld = x->ld; int accum = *xflag;
+            if (cf.ngate) {
+                accum = cf.accum_in ? (int)*xflag : 0;
+                if (cf.raw) { py = cf.raw->g; pld = cf.raw->ld; accum = *cf.raw_flag; }
+            }
+            auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, py, pld, Cin, w->p, nullptr, accum, /*include_empty=*/!accum);
+            bool first = true;
+            for (auto& a : v) {
+                if (ntap == 1 && !stem && pointwise_f16) a.f16 = 1;
+                if (cf.out_bn) {
+                    a.at_mode = P3D_AT_GRAD; a.x2 = y->p; a.ldx2 = y->ld;
+                    a.gf = bn_grad_fold(cf.out_bn, y->rows(), first);
+                }
+                if (cf.ngate) {
+                    if (v.size() != 1) throw P3dError("gated input gradient with more than one residue class");
+                    a.ngate = cf.ngate; a.raw_store = cf.raw ? 1 : 0;
+                    for (int q = 0; q < cf.ngate; ++q) a.gate[q] = bn_gate(cf.gate[q]);
+                    if (!c.dry) {
+                        IgemmArgs t = a; t.zeros = g_zero_page; t.nans = g_nan_page;
+                        const int mt = p3d_igemm2_mtiles(t, p3d_igemm2_plan(t, 1));
+                        for (int q = 0; q < cf.ngate; ++q) {
+                            if (mt > cf.gate[q].bn->gpart_cap) throw P3dError("gradient partials overflow their arena slot");
+                            cf.gate[q].bn->gnparts = mt;
+                        }
+                    }
+                }
+                first = false;
+            }
+            run_igemm_group(c, v, py, pld, x->rows(), Cin, accum != 0, nullptr);
+            queue_wgrad(c, wa);      // after the input gradient: its block 0 published the coefficients this one reads
         };
         ops.push_back(op);
         return y;
@@ -840,8 +1018,10 @@ struct p3d_handle {
     }
 
     // BN finalize + fused normalise / ReLU / add pass (modes in p3d_kernels.h) and its backward.
+    // fused_site: with BatchNorm fusion on (Ctx::fuse) this pass does not run -- its consumers normalise on their operand
+    // paths and the producing convs own the parameter gradients (conv(): ConvFuse); it runs when fusion is off.
     Act* bn_apply(const std::string& opname, int mode, Act* y1, BN* bn1, Act* y2, BN* bn2, Act* out, const std::string& out_name,
-                  bool dropout = false) {
+                  bool dropout = false, bool fused_site = false) {
         if (!out) out = new_act(out_name, y1->N, y1->D, y1->H, y1->W, y1->C);
         else if (!out_name.empty()) named[out_name] = out;
         consume(y1);                                 // y1 is a raw conv output: this op is its only consumer
@@ -863,8 +1043,24 @@ struct p3d_handle {
         const std::string kn_bapply = "bn_bwd_apply_kernel<" + std::to_string(mode) + ">";
         op.flops = 0; op.bytes = tens * (y2 ? 3 : 2);
         op.bflops = 0; op.bbytes = tens * (y2 ? 7 : 5);
-        op.owns = {bn1->gamma, bn1->beta};
-        if (two) { op.owns.push_back(bn2->gamma); op.owns.push_back(bn2->beta); }
+        if (!fused_site) {
+            op.owns = {bn1->gamma, bn1->beta};
+            if (two) { op.owns.push_back(bn2->gamma); op.owns.push_back(bn2->beta); }
+        } else {
+            if (mode != 0 && mode != 3 && mode != 4) throw P3dError("only the bn -> relu passes inside a bottleneck fuse");
+            // reading the (never stored) normalised tensor after a fused forward: the plain apply pass on the published tables
+            out->materialize = [=](hipStream_t st) {
+                BnApplyArgs a;
+                memset(&a, 0, sizeof(a));
+                a.mode = mode; a.M = M; a.C = C;
+                a.y1 = y1->p; a.ld1 = y1->ld; a.scale1 = bn1->scale; a.shift1 = bn1->shift;
+                if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; }
+                if (two) { a.scale2 = bn2->scale; a.shift2 = bn2->shift; }
+                a.z = out->p; a.ldz = out->ld;
+                if (mode == 4 && y2->materialize) y2->materialize(st);      // ST_C adds relu(bnS(yS)), itself never stored
+                HIPCHECK(p3d_bn_apply(a, st));
+            };
+        }
         const bool small = bn_is_small(M, C, dropout);
         auto small_args = [=](const Ctx& c) {
             BnSmallArgs a;
@@ -887,6 +1083,7 @@ struct p3d_handle {
         const std::string kn_sb = "bn_small_bwd_kernel<" + std::to_string(mode) + ">";
         const int R = y1->D * y1->H * y1->W;
         op.fwd = [=](const Ctx& c) {
+            if (fused_site && c.fuse) return;
             if (c.per_sample && (bn1->follows_flag ? c.training : true)) {
                 // B independent batch-of-1 normalisations: per-(clip, channel) statistics over D*H*W, i.e. the
                 // GroupNorm machinery with one channel per group and BN's epsilon
@@ -954,6 +1151,7 @@ struct p3d_handle {
             launch(c, kn_apply.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_apply(a, c.s); });
         };
         op.bwd = [=](const Ctx& c) {
+            if (fused_site && c.fuse) return;
             if (small) {
                 BnSmallArgs sa = small_args(c);
                 sa.batch1 = bn1->used_batch; sa.batch2 = two ? bn2->used_batch : 0;
@@ -1352,49 +1550,77 @@ struct p3d_handle {
         const int kS[3] = {1, 3, 3}, kT[3] = {3, 1, 1};
         const std::string B = "block" + sid + "/";
         // variable creation order matters for BN auto-naming
+        // BatchNorm fusion (ConvFuse): bn1, bnS, bnT and their ReLUs ride on the operand paths of the convs around them;
+        // only bn3 (+ residual) keeps a pass of its own.  Every bn_apply below marked fused_site runs only with fusion off.
         Param* w1 = conv_weight("conv3_" + sid + "_1", {1, 1, 1, inplanes, planes});
         BN* bn1 = add_bn("", planes, false);
-        Act* y1 = conv(B + "conv1", x, w1, nullptr, one, s, planes, bn1, "");
-        Act* z1 = bn_apply(B + "bn1", 0, y1, bn1, nullptr, nullptr, nullptr, B + "conv1_bn_relu");
+        const ConvGeo g1 = make_geo(x->D, x->H, x->W, one, s);
+        const bool fz = (int64_t)x->N * g1.O[0] * g1.O[1] * g1.O[2] <= fuse_max_rows;      // this bottleneck is built fusable
+        ConvFuse f1; if (fz) f1.out_bn = bn1;
+        Act* y1 = conv(B + "conv1", x, w1, nullptr, one, s, planes, bn1, "", false, false, false, &f1);
+        Act* z1 = bn_apply(B + "bn1", 0, y1, bn1, nullptr, nullptr, nullptr, B + "conv1_bn_relu", false, /*fused_site=*/fz);
         const std::string nm = std::string("ST") + st + "_" + sid + "_2";
         Act* stout = nullptr;
+        ConvFuse f3;                 // conv3's view of the ST output
         if (st == 'A') {          // p3d.py:56-63
             Param* wS = conv_weight(nm + "_S", {1, 3, 3, planes, planes});
             Param* bS = conv_weight(nm + "_S_bias", {planes});
             BN* bnS = add_bn("", planes, false);
-            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "");
-            Act* zS = bn_apply(B + "bnS", 0, yS, bnS, nullptr, nullptr, nullptr, "");
+            ConvFuse fS; fS.at = P3D_AT_RELU1; fS.src[0] = {y1, bn1, 1}; fS.ngate = 1; fS.gate[0] = {y1, bn1, 0}; fS.out_bn = bnS;
+            if (!fz) fS = ConvFuse();
+            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, false, &fS);
+            Act* zS = bn_apply(B + "bnS", 0, yS, bnS, nullptr, nullptr, nullptr, "", false, fz);
             Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
             Param* bT = conv_weight(nm + "_T_bias", {planes});
             BN* bnT = add_bn("", planes, false);
-            Act* yT = conv(B + "convT", zS, wT, bT, kT, one, planes, bnT, "");
-            stout = bn_apply(B + "bnT", 0, yT, bnT, nullptr, nullptr, nullptr, B + "st");
+            ConvFuse fT; fT.at = P3D_AT_RELU1; fT.src[0] = {yS, bnS, 1}; fT.ngate = 1; fT.gate[0] = {yS, bnS, 0}; fT.out_bn = bnT;
+            if (!fz) fT = ConvFuse();
+            Act* yT = conv(B + "convT", zS, wT, bT, kT, one, planes, bnT, "", false, false, false, &fT);
+            stout = bn_apply(B + "bnT", 0, yT, bnT, nullptr, nullptr, nullptr, B + "st", false, fz);
+            f3.at = P3D_AT_RELU1; f3.src[0] = {yT, bnT, 1}; f3.ngate = 1; f3.gate[0] = {yT, bnT, 0};
         } else if (st == 'B') {   // p3d.py:65-72
             Param* wS = conv_weight(nm + "_S", {1, 3, 3, planes, planes});
             Param* bS = conv_weight(nm + "_S_bias", {planes});
             BN* bnS = add_bn("", planes, false);
-            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, /*fwd_on_side=*/true);
+            // z1 feeds both siblings: convS (registered first, so last in backward) folds and publishes bn1 in the forward and,
+            // in the backward, adds the raw gradient convT left in z1->g, gates it and reduces for bn1
+            ConvFuse fS; fS.at = P3D_AT_RELU1; fS.src[0] = {y1, bn1, 1}; fS.ngate = 1; fS.gate[0] = {y1, bn1, 0}; fS.accum_in = true; fS.out_bn = bnS;
+            if (!fz) fS = ConvFuse();
+            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, /*fwd_on_side=*/true, &fS);
             Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
             Param* bT = conv_weight(nm + "_T_bias", {planes});
             BN* bnT = add_bn("", planes, false);
-            Act* yT = conv(B + "convT", z1, wT, bT, kT, one, planes, bnT, "");
+            ConvFuse fT; fT.at = P3D_AT_RELU1; fT.src[0] = {y1, bn1, 2}; fT.out_bn = bnT;
+            if (!fz) fT = ConvFuse();
+            Act* yT = conv(B + "convT", z1, wT, bT, kT, one, planes, bnT, "", false, false, false, &fT);
             join_side(B + "joinST");
-            stout = bn_apply(B + "bnST", 3, yS, bnS, yT, bnT, nullptr, B + "st");
+            stout = bn_apply(B + "bnST", 3, yS, bnS, yT, bnT, nullptr, B + "st", false, fz);
+            f3.at = P3D_AT_RELU2; f3.src[0] = {yS, bnS, 1}; f3.src[1] = {yT, bnT, 1};
+            f3.ngate = 2; f3.gate[0] = {yS, bnS, 0}; f3.gate[1] = {yT, bnT, 0};
         } else {                  // p3d.py:74-81
             Param* wS = conv_weight(nm + "_S", {1, 3, 3, planes, planes});
             Param* bS = conv_weight(nm + "_S_bias", {planes});
             BN* bnS = add_bn("", planes, false);
-            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "");
-            Act* zS = bn_apply(B + "bnS", 0, yS, bnS, nullptr, nullptr, nullptr, "");
+            ConvFuse fS; fS.at = P3D_AT_RELU1; fS.src[0] = {y1, bn1, 1}; fS.ngate = 1; fS.gate[0] = {y1, bn1, 0}; fS.out_bn = bnS;
+            if (!fz) fS = ConvFuse();
+            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, false, &fS);
+            Act* zS = bn_apply(B + "bnS", 0, yS, bnS, nullptr, nullptr, nullptr, "", false, fz);
             Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
             Param* bT = conv_weight(nm + "_T_bias", {planes});
             BN* bnT = add_bn("", planes, false);
-            Act* yT = conv(B + "convT", zS, wT, bT, kT, one, planes, bnT, "");
-            stout = bn_apply(B + "bnT", 4, yT, bnT, zS, nullptr, nullptr, B + "st");
+            // zS also reaches conv3 through the skip: conv3's input gradient leaves its raw result in zS->g, convT's adds its
+            // own, gates and reduces for bnS
+            ConvFuse fT; fT.at = P3D_AT_RELU1; fT.src[0] = {yS, bnS, 1}; fT.ngate = 1; fT.gate[0] = {yS, bnS, 0}; fT.accum_in = true; fT.out_bn = bnT;
+            if (!fz) fT = ConvFuse();
+            Act* yT = conv(B + "convT", zS, wT, bT, kT, one, planes, bnT, "", false, false, false, &fT);
+            stout = bn_apply(B + "bnT", 4, yT, bnT, zS, nullptr, nullptr, B + "st", false, fz);
+            f3.at = P3D_AT_RELU2; f3.src[0] = {yS, bnS, 0}; f3.src[1] = {yT, bnT, 1};
+            f3.ngate = 1; f3.gate[0] = {yT, bnT, 0}; f3.raw = zS; f3.raw_flag = zS->last_flag;      // the flag of bnT's skip read
         }
+        if (!fz) f3 = ConvFuse();
         Param* w3 = conv_weight("conv3_" + sid + "_3", {1, 1, 1, planes, planes * 4});
         BN* bn3 = add_bn("", planes * 4, false);
-        Act* y3 = conv(B + "conv3", stout, w3, nullptr, one, one, planes * 4, bn3, "");
+        Act* y3 = conv(B + "conv3", stout, w3, nullptr, one, one, planes * 4, bn3, "", false, false, false, &f3);
         if (first) {              // p3d.py:124-127
             Param* wp = conv_weight("dw3d_" + sid, {1, 1, 1, inplanes, planes * 4});
             BN* bnp = add_bn("", planes * 4, false);
@@ -1846,9 +2072,14 @@ struct p3d_handle {
     // Parameters and moving statistics are not touched.
     void tune_plans() {
         Ctx c; c.training = true; c.s = stream;
-        run_forward(c);
-        run_loss(c);
-        run_backward(c, false);
+        const bool want = fuse_bn;
+        for (int mode = 0; mode < 2; ++mode) {      // both launch lists: BatchNorm fusion can be switched per handle later
+            fuse_bn = mode == 1;
+            run_forward(c);
+            run_loss(c);
+            run_backward(c, false);
+        }
+        fuse_bn = want;
         HIPCHECK(hipStreamSynchronize(c.s));
         HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
         HIPCHECK(hipStreamSynchronize(c.s));
@@ -1903,6 +2134,8 @@ struct p3d_handle {
         if (stats_count) HIPCHECK(hipMemsetAsync(stats_arena, 0, (size_t)stats_count * sizeof(double), c.s));
         if (zf_bytes) HIPCHECK(hipMemsetAsync(zf, 0, zf_bytes, c.s));
         Ctx cz = c; cz.z0 = zf; cz.z1 = zf + zf_bytes;
+        cz.fuse = fuse_bn && !c.per_sample && !c.dry;
+        last_forward_fused = cz.fuse;
         static const bool no_side_f = getenv("P3D_NO_SIDE_STREAM") != nullptr;
         cz.side = (c.prof || no_side_f || c.dry) ? nullptr : side_stream;      // ST_B sibling convs overlap
         const Ctx& c2 = cz;
@@ -1921,6 +2154,7 @@ struct p3d_handle {
     // first op's own variables after it.  Returns whether Adam ran (false: the caller launches run_adam).
     bool run_backward(const Ctx& c0, bool allreduce, bool with_adam = false) {
         Ctx c = c0; c.z0 = zb; c.z1 = zb + zb_bytes;
+        c.fuse = last_forward_fused && !c.dry;       // the backward follows the forward that produced the activations
         bool adam_done = false;
         static const bool no_side = getenv("P3D_NO_SIDE_STREAM") != nullptr;
         c.side = (c.prof || no_side) ? nullptr : side_stream;      // per-launch profiling keeps one stream
@@ -2223,6 +2457,7 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
             const long mb = atol(e);
             if (mb >= 1) h->bucket_floats = (int64_t)mb * (1 << 18);
         }
+        if (const char* e = getenv("P3D_FUSE_MAX_ROWS")) h->fuse_max_rows = atoll(e);      // A/B runs: which bottlenecks are built fusable
         ensure_zero_page();
         {   // the main stream carries the dependent chain of small launches and the comm stream the all-reduces: both above
             // the side stream's filter gradients (measured: no effect on the step time on this ROCm, 17.98 vs 17.95 ms;
@@ -2396,6 +2631,20 @@ int p3d_set_pointwise_fp16(p3d_handle* h, int enable) {
     API_END
 }
 
+int p3d_debug_force_plan(int igemm_tile, int igemm_splits, int wgrad_tm, int wgrad_tn) {
+    p3d_igemm2_override(igemm_tile, igemm_splits);
+    p3d_wgrad2_force_tile(wgrad_tm, wgrad_tn);
+    return 0;
+}
+
+int p3d_set_bn_fusion(p3d_handle* h, int enable) {
+    API_BEGIN
+    if (!h) throw P3dError("null handle");
+    h->fuse_bn = enable != 0;
+    h->drop_step_graph();
+    API_END
+}
+
 int p3d_predict_windows(p3d_handle* h, const float* x, float* pred) {
     API_BEGIN
     if (!h || !x || !pred) throw P3dError("null argument");
@@ -2484,6 +2733,7 @@ int p3d_get_activation(p3d_handle* h, const char* name, float* host, int64_t cou
     Act* a = it->second;
     if (count != a->rows() * a->C) throw P3dError("activation size mismatch");
     HIPCHECK(hipSetDevice(h->cfg.device));
+    if (a->materialize && h->last_forward_fused) a->materialize(h->stream);
     h->download_act(a, host);
     API_END
 }
@@ -2508,7 +2758,8 @@ int p3d_block_forward(p3d_handle* h, int block_id, const float* in, int64_t in_c
     if (in_count != a->rows() * a->C || out_count != b->rows() * b->C) throw P3dError("block tensor size mismatch");
     HIPCHECK(hipSetDevice(h->cfg.device));
     HIPCHECK(hipMemcpy2DAsync(a->p, (size_t)a->ld * 4, in, (size_t)a->C * 4, (size_t)a->C * 4, (size_t)a->rows(), hipMemcpyHostToDevice, h->stream));
-    Ctx c; c.training = true; c.s = h->stream;
+    Ctx c; c.training = true; c.s = h->stream; c.fuse = h->fuse_bn;
+    h->last_forward_fused = c.fuse;
     if (h->stats_count) HIPCHECK(hipMemsetAsync(h->stats_arena, 0, (size_t)h->stats_count * sizeof(double), c.s));
     for (size_t i = it->second.op0; i < it->second.op1; ++i) h->ops[i].fwd(c);      // (no zero arena: ops zero what they slice)
     h->download_act(b, out);
@@ -2933,7 +3184,7 @@ int p3d_shutdown(void) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return 0;
     hipDeviceSynchronize();
     p3d_release_scratch();
-    if (g_zero_page) { hipFree((void*)g_zero_page); g_zero_page = nullptr; }
+    if (g_zero_page) { hipFree((void*)g_zero_page); g_zero_page = nullptr; g_nan_page = nullptr; }
     API_END
 }
 

@@ -18,11 +18,47 @@
 #define P3D_MAX_TAPS 27
 #define P3D_WGRAD_GROUP 6     // weight-gradient problems one grouped launch can carry (kernel-argument space)
 #define P3D_STAT_REPLICAS 16   // lanes that share a channel's partial sums in the finalize kernels (fixed 4-step shuffle fold)
+#define P3D_FOLD_MAX 32        // fused BatchNorm: up to this many per-tile partials a consuming launch folds itself (else a finalize launch)
 
 struct P3dTap {
     int16_t dd, dh, dw;   // gathered coordinate = g*is + d{d,h,w}
     int16_t widx;         // which [K][N] slab of the weight tensor
 };
+
+// ---- BatchNorm fused into the convolutions' operand paths (reference p3d.py:56-81,88-97: every bn -> relu pair
+//      between two convs of a bottleneck) ---------------------------------------------------------------------------
+// The normalised tensor is never stored: the conv that consumes it reads the RAW output y of the producing conv and
+// applies  relu(scale*y + shift)  to its A fragments between LDS and the matrix cores; the per-channel (scale, shift)
+// come from the producer's per-tile statistics partials, folded in the consumer's prologue (few partials) or by a
+// finalize launch (many).  Backward mirrors it: an input-gradient launch gates its result with the ReLU mask of the
+// BatchNorm OUTPUT it differentiates through and leaves per-tile (sum g, sum g*xhat); the next input-gradient launch
+// (and the filter gradients) read  dy = k1*g + k2*y + k3  on their operand path.
+struct BnFold {            // forward: (scale, shift) of one BatchNorm over C channels
+    const float* gamma; const float* beta;
+    const float* part; int nparts;               // producer's (sum, sumsq) partials [nparts][C][2]; null: read scale / shift below
+    int C;
+    float* scale; float* shift; float* mean; float* invstd;     // written by block 0 when `publish` (else read when part == null)
+    float* moving_mean; float* moving_var;       // momentum-0.99 update by the publisher when update_moving
+    double inv_m;                                // 1 / rows of the normalised tensor
+    float eps; int publish; int update_moving;
+};
+struct BnGradFold {        // backward: dy = k1*g + k2*y + k3  (g: gated gradient of the BN output, y: BN input)
+    const float* gamma; const float* mean; const float* invstd;
+    const float* part; int nparts;               // (sum g, sum g*xhat) partials [nparts][C][2]; null: read coef below
+    int C;
+    float* coef;                                 // [3][C] k1, k2, k3: written by block 0 when `publish`, read by the filter gradients
+    float* dgamma; float* dbeta;                 // BN parameter gradients, written by the publisher
+    double inv_m; int publish;
+};
+struct BnGate {            // epilogue of an input-gradient launch: g = (scale*y + shift > 0) ? v : 0
+    const float* y; int ldy;                     // the BN's input (a conv output) on this launch's output lattice
+    const float* scale; const float* shift; const float* mean; const float* invstd;
+    float* out; int ldo;                         // gated gradient
+    float* part;                                 // [m tiles][Nc][2]  (sum g, sum g*xhat) per output-tile row, plain stores
+};
+enum { P3D_AT_NONE = 0, P3D_AT_RELU1 = 1, P3D_AT_RELU2 = 2, P3D_AT_GRAD = 3 };
+//  RELU1: a = relu(s1*x + t1)                           RELU2: a = relu(s1*x + t1) + relu(s2*x2 + t2)   (ST_B / ST_C sums)
+//  GRAD : a = k1*x + k2*x2 + k3   (x = gated gradient, x2 = BN input); padded taps stay 0
 
 // Implicit-GEMM convolution launch:  Y[m, n] (+)= sum_taps sum_k A[m+tap, k] * B_tap[k, n] (+ bias[n])
 struct IgemmArgs {
@@ -46,26 +82,29 @@ struct IgemmArgs {
     float* statpart;
     int stat_base;
     int accum;            // 1: Y += result (gradient accumulation)
-    int sigmoid;          // 1: store 1/(1+exp(-v)) (unused by the generic path today)
     const float* zeros;   // >= 128 B of zeros in device memory (source for padded / tail lanes)
     // K-slicing (filled by the launcher from the plan): slice s of a tile stores its partial tile to
     // slab[(tile * nsplit + s) * BM*BN], the block whose arrival ticket is the last one sums the slices in slice order
     // (bit-reproducible, unlike atomics), applies bias / accumulate / statistics and writes the output.
     float* slab; unsigned* cnt; int nsplit;
-    int xmap;             // 1: 1-D grid, slice = block % nsplit, tile = block / nsplit (with nsplit = 8 a slice's tiles
-                          // share one XCD's L2 under round-robin dispatch: speed only)
     int f16;              // 1: round the operand fragments to fp16 and use the fp16 MFMA (fp32 accumulate); pointwise convs of configs[4]
+    // fused BatchNorm on the A operand (P3D_AT_*): x2 is the second source on the gathered lattice (RELU2, GRAD)
+    int at_mode;
+    const float* x2; int ldx2;
+    BnFold f1, f2;        // RELU1 / RELU2: the BatchNorms of x and x2
+    BnGradFold gf;        // GRAD
+    const float* nans;    // >= 128 B of quiet NaNs: what padded rows of a RELU-transformed operand read (relu(NaN) = 0: maxNum)
+    // gated epilogue (input gradients through a fused BatchNorm + ReLU): the value v of every output element
+    // (after bias / accumulate) goes raw to y when raw_store, and gated to gate[q].out; ngate = 0: plain store to y
+    int ngate, raw_store;
+    BnGate gate[2];
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
-#if defined(P3D_TUNE_STAMPS)     // tools/micro only: [0] cycles waiting for the stage (vmcnt + barrier), [1] rest of the steps, [2] steps,
-    unsigned long long* stamps;  // [3] prologue cycles, [4] epilogue cycles, [5] kernels -- summed by wave 0 of block 0
-#endif
 };
 
 // Tile and split-K choice of the pipelined kernel (conv_igemm2.hip)
 struct P3dIgemmPlan {
     int bm = 64, bn = 64, splits = 1;
-    int xmap = 0;
     const char* name = "";
 };
 // number of output-tile rows (= statistics partials) a launch with this plan produces
@@ -93,6 +132,14 @@ struct WgradArgs {
     int polite;           // 1: runs beside a chain of small launches whatever its own size -- one block per CU
     int pair;             // 1 (K <= 32): two taps share a 64-row tile (the stem's 28-float kernel rows)
     const float* zeros;   // zero page
+    // fused BatchNorm: operand transforms with per-channel coefficients the forward / the input-gradient launches published
+    int xt;               // gathered operand: 0 plain, 1 relu(xs1*x + xt1), 2 relu(xs1*x + xt1) + relu(xs2*x2 + xt2)
+    const float* x2; int ldx2;
+    const float* xs1; const float* xt1; const float* xs2; const float* xt2;     // [K]
+    int dyt;              // dense operand: 0 plain, 1 dcoef[0][n]*dy + dcoef[1][n]*dy2 + dcoef[2][n]
+    const float* dy2; int ldy2;
+    const float* dcoef;   // [3][Nc]
+    const float* nans;    // NaN page (needed when xt != 0)
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
 };
@@ -107,10 +154,11 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split);
 void p3d_tune_begin(hipStream_t s);
 void p3d_tune_end();
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipStream_t s);
-void p3d_igemm2_override(int tile, int splits, int xmap);   // tools/micro sweeps: -1 / 0 / -1 = no override
+void p3d_igemm2_override(int tile, int splits);   // test / tools hook: force the tile (0: 64x64, 1: 128x64, 2: 128x128) and the K-slice count; -1 / 0 = no override
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s);   // up to P3D_WGRAD_GROUP problems, one launch
 const char* p3d_wgrad2_variant(const WgradArgs& a);
+void p3d_wgrad2_force_tile(int tm, int tn);      // test hook: tile of single-problem launches (64 / 128 each); 0, 0 = the plan's choice
 
 // ---- BatchNorm (tf.layers.batch_normalization, rank-5, eps 1e-3) ------------------------------
 struct BnParams {          // device pointers, all [C]
@@ -128,6 +176,9 @@ hipError_t p3d_bn_finalize(const BnParams& bn, long M, int use_batch, int update
 // (for producers that cannot do it in their epilogue)
 int p3d_bn_stats_parts(long M, int C);
 hipError_t p3d_bn_stats(const float* y, int ld, long M, int C, float* statpart, hipStream_t s);
+
+// coefficients of a fused BatchNorm's backward from many partials (few: the consuming launch folds them itself)
+hipError_t p3d_bn_grad_finalize(const BnGradFold& f, hipStream_t s);
 
 // Fused normalise/activate/add passes.  Modes (reference p3d.py lines in brackets):
 //  0: z = relu(bn1(y1))                         [58-59, 88+97, 173-174, 201-202]

@@ -166,6 +166,10 @@ class P3DSession:
         """BASELINE configs[4]: 1x1x1 convs on the fp16 matrix cores (fp32 accumulate, fp32 storage); fp16-level parity."""
         check(lib().p3d_set_pointwise_fp16(self._h, int(bool(enable))))
 
+    def set_bn_fusion(self, enable=True):
+        """BatchNorm + ReLU between the convs of a bottleneck on the convs' operand paths (default) or as passes of their own."""
+        check(lib().p3d_set_bn_fusion(self._h, int(bool(enable))))
+
     def predict_windows(self, x):
         """B windows of gen_pred.py:100-168 at once: row k equals forward(x[k:k+1], training=False) of a batch-1
         session, i.e. every batch-statistics BN normalises each clip by its own statistics."""

@@ -134,11 +134,19 @@ def test_bias_add_grad(rows, c):
 
 @pytest.mark.parametrize("tile", ["64x64", "64x128", "128x64", "128x128"])
 @pytest.mark.parametrize("xs,k,co", [((2, 4, 14, 14, 256), (1, 3, 3), 128), ((1, 4, 8, 8, 128), (3, 3, 3), 192), ((3, 2, 9, 7, 136), (1, 1, 1), 132)])
-def test_filter_gradient_tile_shapes(tile, xs, k, co, monkeypatch):
+def test_filter_gradient_tile_shapes(tile, xs, k, co):
     """Every tile shape of the filter-gradient kernel (conv_wgrad2.hip) on the same problems -- ragged K / Nc tails included
     (136 x 132) -- against the oracle, and bit-identical run to run (fixed cut order)."""
-    from sap3d_tensorflow_amd import ops
-    monkeypatch.setenv("P3D_WGRAD_TILE", tile)
+    from sap3d_tensorflow_amd import lib, ops
+    tm, tn = (int(v) for v in tile.split("x"))
+    lib().p3d_debug_force_plan(-1, 0, tm, tn)
+    try:
+        _filter_gradient_case(ops, xs, k, co)
+    finally:
+        lib().p3d_debug_force_plan(-1, 0, 0, 0)
+
+
+def _filter_gradient_case(ops, xs, k, co):
     rng = np.random.default_rng(5)
     x = rnd(rng, xs)
     s = (1, 1, 1)
