@@ -159,8 +159,8 @@ def main():
     ap.add_argument("--size", type=int, default=112, help="clip height = width (BASELINE configs[4] uses 32 frames of 224)")
     ap.add_argument("--pointwise", default="fp32", choices=["fp32", "fp16"],
                     help="fp16: 1x1x1 convs on the fp16 MFMA with fp32 accumulate (BASELINE configs[4]); fp16-level parity")
-    ap.add_argument("--bn-fusion", default="on", choices=["on", "off"],
-                    help="off: every BatchNorm is a pass of its own (the round-2 launch list), for A/B runs")
+    ap.add_argument("--bn-fusion", default="default", choices=["default", "off", "fwd", "full"],
+                    help="A/B runs: BatchNorm passes of their own / fused into the convs in the forward pass / in both passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--dump-launches", default=None, help="write every launch record of the profiled step to this CSV")
@@ -187,8 +187,8 @@ def main():
                       world_size=world, rank=rank, seed=1)
     if args.pointwise == "fp16":
         sess.set_pointwise_fp16(True)
-    if args.bn_fusion == "off":
-        sess.set_bn_fusion(False)
+    if args.bn_fusion != "default":
+        sess.set_bn_fusion({"off": 0, "fwd": 1, "full": 2}[args.bn_fusion])
     if world > 1 and not rehearsal:
         sess.comm_init(plane.share_from_rank0(P3DSession.comm_unique_id))
     x = synthetic.synthetic_clip(rank, (B, T, S, S, 3))

@@ -107,9 +107,11 @@ int p3d_backward(p3d_handle* h, const float* x, const float* y, float dropout_ra
 int p3d_set_pointwise_fp16(p3d_handle* h, int enable);
 
 /* BatchNorm fusion (no reference counterpart: an execution choice, the arithmetic is tf.layers.batch_normalization's either
- * way, p3d.py:56-81,88-97).  On (the default): the bn -> relu pairs between the convs of a bottleneck are applied on the
- * operand paths of the neighbouring convolutions and never stored.  Off: every BatchNorm is a pass of its own (the
- * round-2 launch list); kept for A/B timing and for parity tests of one path against the other. */
+ * way, p3d.py:56-81,88-97).  When on, the bn -> relu pairs between the convs of a small-tensor bottleneck are applied on the
+ * operand paths of the neighbouring convolutions and never stored (fewer launches; measured no faster on one MI355X at 8
+ * clips, so the default is off).  enable = 0: every BatchNorm is a pass of its own (the
+ * round-2 launch list); 1: the forward pass is fused, BatchNorm's backward keeps its launches (the filter gradients read
+ * the never-stored activations through the transform); 2: the backward pass is fused as well. */
 int p3d_set_bn_fusion(p3d_handle* h, int enable);
 
 /* tf.train.AdamOptimizer(lr, beta1, beta2, epsilon) (train.py:168; defaults 1e-4, .9, .999, 1e-8). */

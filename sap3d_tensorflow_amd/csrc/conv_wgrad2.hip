@@ -19,8 +19,8 @@
 // FUSED BatchNorm (round 3, template parameter FUSED; see p3d_kernels.h "BatchNorm fused into the convolutions' operand
 // paths"): a problem may read its gathered operand as relu(s1*x + t1) [+ relu(s2*x2 + t2)] and its dense operand as
 // k1*dy + k2*dy2 + k3 -- the normalised activations and BatchNorm's input gradients are never stored.  The per-channel
-// coefficients sit in registers (a lane's fragment channel is fixed for the whole kernel) and are applied between
-// ds_read and MFMA; padded / out-of-range rows of a relu-transformed operand read a NaN page (relu(NaN) = 0).
+// coefficients sit in registers (the channels of a lane's DMA chunks are fixed for the whole kernel); the lane that fetched
+// a chunk transforms it on its way into the tile the fragments are read from, padded / out-of-range chunks stay zero.
 #include "p3d_kernels.h"
 #include <algorithm>
 #include <cstdio>
@@ -71,7 +71,7 @@ struct WProb {
 };
 struct WGroup {
     int nprob;
-    const float* zeros; const float* nans;
+    const float* zeros;
     float* slab; unsigned* cnt;
     int kstride;         // slab index of (slot, cut) = slot * kstride + cut
     WProb p[P3D_WGRAD_GROUP];
@@ -116,68 +116,145 @@ __device__ __forceinline__ void wloader_init(const WProb& p, WState<BM / 32, BN 
     }
 }
 
-// Always the same number of loads per step for a block (rows past the slice end, padded rows and channel tails read the
-// pad page): LA + LB, plus LA when the gathered operand has a second source, plus LB when the dense one has.
-template <int BM, int BN, bool FUSED>
-__device__ __forceinline__ void issue_stage(const WProb& p, const float* zeros, const float* apad, int tdd, int tdh, int tdw,
-                                            float* __restrict__ a_dst, float* __restrict__ a2_dst, float* __restrict__ b_dst,
-                                            float* __restrict__ b2_dst, WState<BM / 32, BN / 32>& st, unsigned me, bool two_x,
-                                            bool two_dy, int wave, int lane) {
+// Always LA + LB loads (rows past the slice end, padded rows and channel tails read the zero page).
+template <int BM, int BN>
+__device__ __forceinline__ void advance_rows(const WProb& p, WState<BM / 32, BN / 32>& st, int i) {
+    st.m[i] += BKM;
+    int gw = st.gw[i] + BKM;
+    const int q1 = (int)(((unsigned)gw * st.rGw) >> 16);
+    gw -= q1 * p.Gw;
+    int gh = st.gh[i] + q1;
+    const int q2 = (int)(((unsigned)gh * st.rGh) >> 16);
+    gh -= q2 * p.Gh;
+    int gd = st.gd[i] + q2;
+    const int q3 = (int)(((unsigned)gd * st.rGd) >> 16);
+    gd -= q3 * p.Gd;
+    st.gw[i] = gw; st.gh[i] = gh; st.gd[i] = gd; st.n[i] += q3;
+}
+template <int BM, int BN>
+__device__ __forceinline__ void issue_stage(const WProb& p, const float* zeros, int tdd, int tdh, int tdw, float* __restrict__ a_dst,
+                                            float* __restrict__ b_dst, WState<BM / 32, BN / 32>& st, unsigned me, int wave,
+                                            int lane) {
     constexpr int LA = BM / 32, LB = BN / 32;
     const float* zp = zeros + 4 * (lane & 7);
-    const float* ap = apad + 4 * (lane & 7);        // NaN page under a relu transform, else zeros
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int id = st.gd[i] * p.isd + tdd, ih = st.gh[i] * p.ish + tdh, iw = st.gw[i] * p.isw + tdw;
         const bool ok = st.m[i] < me && st.kc[i] < p.K && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
                         (unsigned)iw < (unsigned)p.Wi;
-        const long long row = (((long long)st.n[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw;
-        glds16(ok ? p.x + row * p.ldx + st.kc[i] : ap, a_dst + (i * 4 + wave) * 256);
-        if (FUSED && two_x) glds16(ok ? p.x2 + row * p.ldx2 + st.kc[i] : ap, a2_dst + (i * 4 + wave) * 256);
-        // advance 32 positions
-        st.m[i] += BKM;
-        int gw = st.gw[i] + BKM;
-        const int q1 = (int)(((unsigned)gw * st.rGw) >> 16);
-        gw -= q1 * p.Gw;
-        int gh = st.gh[i] + q1;
-        const int q2 = (int)(((unsigned)gh * st.rGh) >> 16);
-        gh -= q2 * p.Gh;
-        int gd = st.gd[i] + q2;
-        const int q3 = (int)(((unsigned)gd * st.rGd) >> 16);
-        gd -= q3 * p.Gd;
-        st.gw[i] = gw; st.gh[i] = gh; st.gd[i] = gd; st.n[i] += q3;
+        const float* src = ok ? p.x + ((((long long)st.n[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw) * p.ldx + st.kc[i] : zp;
+        glds16(src, a_dst + (i * 4 + wave) * 256);
+        advance_rows<BM, BN>(p, st, i);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         const bool ok = st.bm[i] < me && st.bok[i];
         glds16(ok ? st.bptr[i] : zp, b_dst + (i * 4 + wave) * 256);
-        if (FUSED && two_dy) glds16(ok ? p.dy2 + (long long)st.bm[i] * p.ldy2 + st.bnc[i] : zp, b2_dst + (i * 4 + wave) * 256);
         st.bm[i] += BKM;
         st.bptr[i] += (long long)BKM * p.ldy;
     }
 }
 
-// Per-lane coefficients of the operand transforms: a lane's fragment channel (A) and column (B) never change.
+// ---- fused BatchNorm: both operands take a detour through raw LDS slots (conv_igemm2.hip, "fused BatchNorm") ----------
+// The lane DMAs its chunks (of one or two sources per operand) into raw slots STAGES steps ahead; one step before use it
+// reads ITS OWN chunks back, applies the per-channel transform -- its chunk's channels never change, so the coefficients
+// sit in registers -- keeps padded / out-of-range chunks at zero, and writes the chunk to its place in a two-slot ring of
+// finished tiles.  The fragment reads and MFMAs are the plain kernel's.
+struct WMeta { unsigned aok, bok; };     // bit i: chunk i of the step is a real element run
 template <int BM, int BN>
-struct WCoef {
-    float s1[BM / 64], t1[BM / 64], s2[BM / 64], t2[BM / 64];      // x:  relu(s1*x + t1) + relu(s2*x2 + t2)
-    float k1[BN / 64], k2[BN / 64], k3[BN / 64];                    // dy: k1*dy + k2*dy2 + k3
+struct WRaw {       // raw DMA targets of one in-flight step and the ring slot its transformed tiles go to
+    float* a; float* a2; float* b; float* b2;
 };
+template <int BM, int BN>
+__device__ __forceinline__ void issue_raw(const WProb& p, const float* zeros, int tdd, int tdh, int tdw, const WRaw<BM, BN> d, WMeta& mt,
+                                          WState<BM / 32, BN / 32>& st, unsigned me, bool two_x, bool two_dy, int wave, int lane) {
+    constexpr int LA = BM / 32, LB = BN / 32;
+    const float* zp = zeros + 4 * (lane & 7);
+    mt.aok = 0; mt.bok = 0;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int id = st.gd[i] * p.isd + tdd, ih = st.gh[i] * p.ish + tdh, iw = st.gw[i] * p.isw + tdw;
+        const bool ok = st.m[i] < me && st.kc[i] < p.K && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
+                        (unsigned)iw < (unsigned)p.Wi;
+        mt.aok |= (ok ? 1u : 0u) << i;
+        const long long row = (((long long)st.n[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw;
+        glds16(ok ? p.x + row * p.ldx + st.kc[i] : zp, d.a + (i * 4 + wave) * 256);
+        if (two_x) glds16(ok ? p.x2 + row * p.ldx2 + st.kc[i] : zp, d.a2 + (i * 4 + wave) * 256);
+        advance_rows<BM, BN>(p, st, i);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const bool ok = st.bm[i] < me && st.bok[i];
+        mt.bok |= (ok ? 1u : 0u) << i;
+        glds16(ok ? st.bptr[i] : zp, d.b + (i * 4 + wave) * 256);
+        if (two_dy) glds16(ok ? p.dy2 + (long long)st.bm[i] * p.ldy2 + st.bnc[i] : zp, d.b2 + (i * 4 + wave) * 256);
+        st.bm[i] += BKM;
+        st.bptr[i] += (long long)BKM * p.ldy;
+    }
+}
+struct WCoef {      // this lane's four channels (x) / columns (dy)
+    float4 s1, t1, s2, t2;      // x:  relu(s1*x + t1) + relu(s2*x2 + t2)
+    float4 k1, k2, k3;          // dy: k1*dy + k2*dy2 + k3
+};
+template <int BM, int BN>
+struct WXIn { float4 au[BM / 32], av[BM / 32], bu[BN / 32], bv[BN / 32]; };
+template <int BM, int BN>
+__device__ __forceinline__ void raw_load(const WRaw<BM, BN> r, WXIn<BM, BN>& x, bool two_x, bool two_dy, int wave, int lane) {
+    constexpr int LA = BM / 32, LB = BN / 32;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int at = (i * 4 + wave) * 256 + lane * 4;
+        x.au[i] = *reinterpret_cast<const float4*>(r.a + at);
+        x.av[i] = two_x ? *reinterpret_cast<const float4*>(r.a2 + at) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int at = (i * 4 + wave) * 256 + lane * 4;
+        x.bu[i] = *reinterpret_cast<const float4*>(r.b + at);
+        x.bv[i] = two_dy ? *reinterpret_cast<const float4*>(r.b2 + at) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ float4 wrelu4(float4 s, float4 u, float4 t) {
+    return make_float4(fmaxf(fmaf(s.x, u.x, t.x), 0.f), fmaxf(fmaf(s.y, u.y, t.y), 0.f), fmaxf(fmaf(s.z, u.z, t.z), 0.f),
+                       fmaxf(fmaf(s.w, u.w, t.w), 0.f));
+}
+template <int BM, int BN>
+__device__ __forceinline__ void transform_store(const WXIn<BM, BN>& x, const WMeta& mt, const WCoef& cf, int xt, int dyt,
+                                                float* __restrict__ a_dst, float* __restrict__ b_dst, int wave, int lane) {
+    constexpr int LA = BM / 32, LB = BN / 32;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        float4 a = x.au[i];
+        if (xt) {
+            a = wrelu4(cf.s1, a, cf.t1);
+            if (xt == 2) { const float4 q = wrelu4(cf.s2, x.av[i], cf.t2); a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+        }
+        if (!((mt.aok >> i) & 1u)) a = zero;
+        *reinterpret_cast<float4*>(a_dst + (i * 4 + wave) * 256 + lane * 4) = a;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        float4 b = x.bu[i];
+        if (dyt) {
+            const float4 v = x.bv[i];
+            b = make_float4(fmaf(cf.k1.x, b.x, fmaf(cf.k2.x, v.x, cf.k3.x)), fmaf(cf.k1.y, b.y, fmaf(cf.k2.y, v.y, cf.k3.y)),
+                            fmaf(cf.k1.z, b.z, fmaf(cf.k2.z, v.z, cf.k3.z)), fmaf(cf.k1.w, b.w, fmaf(cf.k2.w, v.w, cf.k3.w)));
+        }
+        if (!((mt.bok >> i) & 1u)) b = zero;
+        *reinterpret_cast<float4*>(b_dst + (i * 4 + wave) * 256 + lane * 4) = b;
+    }
+}
 
 // All fragment reads of a stage are issued before its first MFMA (one exposed LDS latency per step instead of one per
 // pair of MFMAs); the stage is then consumed in two halves so that the next refill's address arithmetic and DMA issue
-// run while the first half's MFMAs execute (same arrangement as conv_igemm2.hip's pipe_step).  The operand transforms are
-// applied pair by pair inside the MFMA loop: a pair's few VALU operations issue in the shadow of the previous MFMA.
-template <int BM, int BN, bool FUSED>
-struct WFrags {
-    float a[BKM / 2][BM / 64]; float b[BKM / 2][BN / 64];
-    float a2[FUSED ? BKM / 2 : 1][BM / 64]; float b2[FUSED ? BKM / 2 : 1][BN / 64];
-};
+// run while the first half's MFMAs execute (same arrangement as conv_igemm2.hip's pipe_step).
+template <int BM, int BN>
+struct WFrags { float a[BKM / 2][BM / 64]; float b[BKM / 2][BN / 64]; };
 
-template <int BM, int BN, bool FUSED>
-__device__ __forceinline__ void load_wfrags(const float* __restrict__ a_st, const float* __restrict__ a2_st,
-                                            const float* __restrict__ b_st, const float* __restrict__ b2_st,
-                                            WFrags<BM, BN, FUSED>& f, bool two_x, bool two_dy, int wm, int wn, int h, int l31) {
+template <int BM, int BN>
+__device__ __forceinline__ void load_wfrags(const float* __restrict__ a_st, const float* __restrict__ b_st, WFrags<BM, BN>& f,
+                                            int wm, int wn, int h, int l31) {
     constexpr int TM = BM / 64, TN = BN / 64;
 #pragma unroll
     for (int k2 = 0; k2 < BKM / 2; ++k2) {
@@ -186,46 +263,16 @@ __device__ __forceinline__ void load_wfrags(const float* __restrict__ a_st, cons
 #pragma unroll
         for (int j = 0; j < TN; ++j) f.b[k2][j] = b_st[(2 * k2 + h) * BN + wn * (BN / 2) + j * 32 + l31];
     }
-    if constexpr (FUSED) {
-        if (two_x) {
-#pragma unroll
-            for (int k2 = 0; k2 < BKM / 2; ++k2)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) f.a2[k2][i] = a2_st[(2 * k2 + h) * BM + wm * (BM / 2) + i * 32 + l31];
-        }
-        if (two_dy) {
-#pragma unroll
-            for (int k2 = 0; k2 < BKM / 2; ++k2)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) f.b2[k2][j] = b2_st[(2 * k2 + h) * BN + wn * (BN / 2) + j * 32 + l31];
-        }
-    }
 }
-// nvalid: positions of this step inside the block's range (32 except in the last step) -- the bias sums skip the others
-template <int BM, int BN, bool FUSED, int K0, int K1>
-__device__ __forceinline__ void mfma_wfrags(WFrags<BM, BN, FUSED>& f, const WCoef<BM, BN>& cf, int xt, int dyt,
-                                            f32x16 (&acc)[BM / 64][BN / 64], float (&bsum)[BN / 64], bool do_bias, int nvalid, int h) {
+// the bias gradient (column sums of dY) rides along in registers: rows past the end of the range are zero in LDS
+template <int BM, int BN, int K0, int K1>
+__device__ __forceinline__ void mfma_wfrags(const WFrags<BM, BN>& f, f32x16 (&acc)[BM / 64][BN / 64], float (&bsum)[BN / 64], bool do_bias) {
     constexpr int TM = BM / 64, TN = BN / 64;
 #pragma unroll
     for (int k2 = K0 / 2; k2 < K1 / 2; ++k2) {
-        if constexpr (FUSED) {
-            if (xt) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    float r = fmaxf(fmaf(cf.s1[i], f.a[k2][i], cf.t1[i]), 0.f);
-                    if (xt == 2) r += fmaxf(fmaf(cf.s2[i], f.a2[k2][i], cf.t2[i]), 0.f);
-                    f.a[k2][i] = r;
-                }
-            }
-            if (dyt) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) f.b[k2][j] = fmaf(cf.k1[j], f.b[k2][j], fmaf(cf.k2[j], f.b2[k2][j], cf.k3[j]));
-            }
-        }
         if (do_bias) {
-            const bool in = (2 * k2 + h) < nvalid;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bsum[j] += in ? f.b[k2][j] : 0.f;
+            for (int j = 0; j < TN; ++j) bsum[j] += f.b[k2][j];
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -234,38 +281,55 @@ __device__ __forceinline__ void mfma_wfrags(WFrags<BM, BN, FUSED>& f, const WCoe
     }
 }
 
-// operand views of one ring stage
-struct WStage { float* a; float* a2; float* b; float* b2; };
-
-template <int BM, int BN, bool FUSED>
-__device__ __forceinline__ void pipe_step(const WProb& p, const float* zeros, const float* apad, int tdd, int tdh, int tdw,
-                                          const WStage dst, const WStage src, f32x16 (&acc)[BM / 64][BN / 64],
-                                          const WCoef<BM, BN>& cf, float (&bsum)[BN / 64], bool do_bias, int nvalid,
-                                          WState<BM / 32, BN / 32>& st, unsigned me, bool two_x, bool two_dy, int wave, int lane,
-                                          int wm, int wn) {
+template <int BM, int BN>
+__device__ __forceinline__ void pipe_step(const WProb& p, const float* zeros, int tdd, int tdh, int tdw, float* __restrict__ a_dst,
+                                          float* __restrict__ b_dst, const float* __restrict__ a_src,
+                                          const float* __restrict__ b_src, f32x16 (&acc)[BM / 64][BN / 64], float (&bsum)[BN / 64],
+                                          bool do_bias, WState<BM / 32, BN / 32>& st, unsigned me, int wave, int lane, int wm,
+                                          int wn) {
+    constexpr int LPS = BM / 32 + BN / 32;
+    wait_vmcnt<(WRing<BM>::stages - 2) * LPS>();
+    __builtin_amdgcn_s_barrier();
+    WFrags<BM, BN> f;
+    load_wfrags<BM, BN>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
+    __builtin_amdgcn_sched_barrier(0);      // keep every read above the MFMAs (hipcc otherwise sinks them back, pair by pair)
+    mfma_wfrags<BM, BN, 0, BKM / 2>(f, acc, bsum, do_bias);
+    issue_stage<BM, BN>(p, zeros, tdd, tdh, tdw, a_dst, b_dst, st, me, wave, lane);
+    mfma_wfrags<BM, BN, BKM / 2, BKM>(f, acc, bsum, do_bias);
+}
+// fused: consume ring slot `cur`; transform the next step's raw chunks into ring slot `nxt`, then re-target that raw slot
+template <int BM, int BN>
+__device__ __forceinline__ void pipe_step_fused(const WProb& p, const float* zeros, int tdd, int tdh, int tdw, const WRaw<BM, BN> raw,
+                                                WMeta& mt, const WCoef& cf, float* __restrict__ a_nxt, float* __restrict__ b_nxt,
+                                                const float* __restrict__ a_cur, const float* __restrict__ b_cur,
+                                                f32x16 (&acc)[BM / 64][BN / 64], float (&bsum)[BN / 64], bool do_bias,
+                                                WState<BM / 32, BN / 32>& st, unsigned me, bool two_x, bool two_dy, int wave, int lane,
+                                                int wm, int wn) {
     constexpr int LA = BM / 32, LB = BN / 32;
     if constexpr (WRing<BM>::stages == 2) {
         wait_vmcnt<0>();
-    } else if constexpr (!FUSED) {
-        wait_vmcnt<LA + LB>();
-    } else {
-        // the loads of one step: LA + LB, + LA / + LB for the second sources (block-uniform)
+    } else {      // one step's loads may still fly: LA + LB, + LA / + LB for second sources (block-uniform)
         if (two_x) { if (two_dy) wait_vmcnt<2 * LA + 2 * LB>(); else wait_vmcnt<2 * LA + LB>(); }
         else { if (two_dy) wait_vmcnt<LA + 2 * LB>(); else wait_vmcnt<LA + LB>(); }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my transformed chunks of this step are in LDS
     __builtin_amdgcn_s_barrier();
-    WFrags<BM, BN, FUSED> f;
-    load_wfrags<BM, BN, FUSED>(src.a, src.a2, src.b, src.b2, f, two_x, two_dy, wm, wn, lane >> 5, lane & 31);
-    __builtin_amdgcn_sched_barrier(0);      // keep every read above the MFMAs (hipcc otherwise sinks them back, pair by pair)
-    const int xt = FUSED ? p.xt : 0, dyt = FUSED ? p.dyt : 0;
-    mfma_wfrags<BM, BN, FUSED, 0, BKM / 2>(f, cf, xt, dyt, acc, bsum, do_bias, nvalid, lane >> 5);
-    issue_stage<BM, BN, FUSED>(p, zeros, apad, tdd, tdh, tdw, dst.a, dst.a2, dst.b, dst.b2, st, me, two_x, two_dy, wave, lane);
-    mfma_wfrags<BM, BN, FUSED, BKM / 2, BKM>(f, cf, xt, dyt, acc, bsum, do_bias, nvalid, lane >> 5);
+    WFrags<BM, BN> f;
+    load_wfrags<BM, BN>(a_cur, b_cur, f, wm, wn, lane >> 5, lane & 31);
+    WXIn<BM, BN> xin;
+    raw_load<BM, BN>(raw, xin, two_x, two_dy, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_wfrags<BM, BN, 0, BKM / 2>(f, acc, bsum, do_bias);
+    transform_store<BM, BN>(xin, mt, cf, p.xt, p.dyt, a_nxt, b_nxt, wave, lane);
+    issue_raw<BM, BN>(p, zeros, tdd, tdh, tdw, raw, mt, st, me, two_x, two_dy, wave, lane);
+    mfma_wfrags<BM, BN, BKM / 2, BKM>(f, acc, bsum, do_bias);
 }
 
 template <int BM, int BN, bool FUSED>
 constexpr size_t wsmem_bytes() {
-    const size_t ring = (size_t)WRing<BM>::stages * BKM * (BM + BN) * 4 * (FUSED ? 2 : 1);
+    constexpr int S = WRing<BM>::stages;
+    // plain: S stages of (A, B).  fused: two finished (A, B) tiles + S - 1 raw slots of (A, A2, B, B2)
+    const size_t ring = FUSED ? (size_t)(2 + 2 * (S - 1)) * BKM * (BM + BN) * 4 : (size_t)S * BKM * (BM + BN) * 4;
     const size_t tile = (size_t)BM * (BN + 4) * 4 + BN * 4 + 16;      // staged tile + bias sums + reducer flag
     return ring > tile ? ring : tile;
 }
@@ -277,9 +341,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
     constexpr int STAGES = WRing<BM>::stages;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);
-    float* Bs = As + STAGES * A_STAGE;
-    float* A2s = Bs + STAGES * B_STAGE;                    // second sources (FUSED only)
-    float* B2s = A2s + STAGES * A_STAGE;
+    float* Bs = As + (FUSED ? 2 : STAGES) * A_STAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -306,7 +368,6 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
         p.x2 = src.x2; p.xs1 = src.xs1; p.xt1 = src.xt1; p.xs2 = src.xs2; p.xt2 = src.xt2; p.dy2 = src.dy2; p.dcoef = src.dcoef;
     }
     const bool two_x = FUSED && p.xt == 2, two_dy = FUSED && p.dyt != 0;
-    const float* apad = (FUSED && p.xt) ? g.nans : g.zeros;
 
     const long long M = (long long)p.N * p.Gd * p.Gh * p.Gw;
     const int KT = p.pair ? 1 : (p.K + BM - 1) / BM, NT = (p.Nc + BN - 1) / BN;
@@ -348,53 +409,71 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) bsum[j] = 0.f;
 
-    WCoef<BM, BN> cf;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) { cf.s1[i] = 0.f; cf.t1[i] = 0.f; cf.s2[i] = 0.f; cf.t2[i] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) { cf.k1[j] = 0.f; cf.k2[j] = 0.f; cf.k3[j] = 0.f; }
-    if constexpr (FUSED) {
-        if (p.xt) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int ch = k0 + wm * (BM / 2) + i * 32 + l31;
-                if (ch < p.K) {
-                    cf.s1[i] = p.xs1[ch]; cf.t1[i] = p.xt1[ch];
-                    if (p.xt == 2) { cf.s2[i] = p.xs2[ch]; cf.t2[i] = p.xt2[ch]; }
-                }
-            }
-        }
-        if (p.dyt) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * (BN / 2) + j * 32 + l31;
-                if (col < p.Nc) { cf.k1[j] = p.dcoef[col]; cf.k2[j] = p.dcoef[p.Nc + col]; cf.k3[j] = p.dcoef[2 * p.Nc + col]; }
-            }
-        }
-    }
-
     WState<BM / 32, BN / 32> st;
     wloader_init<BM, BN>(p, st, (unsigned)ms, k0, n0, wave, lane);
     const unsigned meu = (unsigned)me;
-    int left = (int)(me - ms);                               // positions not yet consumed
-    if (STAGES == 3) {
-        const WStage S0{As, A2s, Bs, B2s}, S1{As + A_STAGE, A2s + A_STAGE, Bs + B_STAGE, B2s + B_STAGE},
-                     S2{As + 2 * A_STAGE, A2s + 2 * A_STAGE, Bs + 2 * B_STAGE, B2s + 2 * B_STAGE};
-        issue_stage<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S0.a, S0.a2, S0.b, S0.b2, st, meu, two_x, two_dy, wave, lane);
-        issue_stage<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S1.a, S1.a2, S1.b, S1.b2, st, meu, two_x, two_dy, wave, lane);
-        for (int base = 0; base < nsteps; base += 3) {
-            pipe_step<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S2, S0, acc, cf, bsum, do_bias, left, st, meu, two_x, two_dy, wave, lane, wm, wn);
-            left -= BKM;
-            if (base + 1 < nsteps) { pipe_step<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S0, S1, acc, cf, bsum, do_bias, left, st, meu, two_x, two_dy, wave, lane, wm, wn); left -= BKM; }
-            if (base + 2 < nsteps) { pipe_step<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S1, S2, acc, cf, bsum, do_bias, left, st, meu, two_x, two_dy, wave, lane, wm, wn); left -= BKM; }
+    if constexpr (!FUSED) {
+        if (STAGES == 3) {
+            float* A0 = As; float* A1 = As + A_STAGE; float* A2 = As + 2 * A_STAGE;
+            float* B0 = Bs; float* B1 = Bs + B_STAGE; float* B2 = Bs + 2 * B_STAGE;
+            issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, st, meu, wave, lane);
+            issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, st, meu, wave, lane);
+            for (int base = 0; base < nsteps; base += 3) {
+                pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A2, B2, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+                if (base + 1 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+                if (base + 2 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, A2, B2, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            }
+        } else {
+            float* A0 = As; float* A1 = As + A_STAGE;
+            float* B0 = Bs; float* B1 = Bs + B_STAGE;
+            issue_stage<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, st, meu, wave, lane);
+            for (int base = 0; base < nsteps; base += 2) {
+                pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A1, B1, A0, B0, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+                if (base + 1 < nsteps) pipe_step<BM, BN>(p, g.zeros, tdd, tdh, tdw, A0, B0, A1, B1, acc, bsum, do_bias, st, meu, wave, lane, wm, wn);
+            }
         }
     } else {
-        const WStage S0{As, A2s, Bs, B2s}, S1{As + A_STAGE, A2s + A_STAGE, Bs + B_STAGE, B2s + B_STAGE};
-        issue_stage<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S0.a, S0.a2, S0.b, S0.b2, st, meu, two_x, two_dy, wave, lane);
+        // raw slots behind the two finished tiles: [S-1] x (A, A2, B, B2)
+        float* rawbase = Bs + 2 * B_STAGE;
+        constexpr int RS = STAGES - 1, RAW_STEP = 2 * (A_STAGE + B_STAGE);
+        WRaw<BM, BN> raw[RS];
+#pragma unroll
+        for (int q = 0; q < RS; ++q) {
+            float* r = rawbase + q * RAW_STEP;
+            raw[q].a = r; raw[q].a2 = r + A_STAGE; raw[q].b = r + 2 * A_STAGE; raw[q].b2 = r + 2 * A_STAGE + B_STAGE;
+        }
+        // this lane's coefficients: its chunk covers channels kc .. kc+3 of x and columns nc .. nc+3 of dy, for the whole kernel
+        WCoef cf;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        cf.s1 = zero4; cf.t1 = zero4; cf.s2 = zero4; cf.t2 = zero4; cf.k1 = zero4; cf.k2 = zero4; cf.k3 = zero4;
+        {
+            const int kc = k0 + (lane % (BM / 4)) * 4, nc = n0 + (lane % (BN / 4)) * 4;
+            if (p.xt && kc < p.K) {
+                cf.s1 = *reinterpret_cast<const float4*>(p.xs1 + kc); cf.t1 = *reinterpret_cast<const float4*>(p.xt1 + kc);
+                if (p.xt == 2) { cf.s2 = *reinterpret_cast<const float4*>(p.xs2 + kc); cf.t2 = *reinterpret_cast<const float4*>(p.xt2 + kc); }
+            }
+            if (p.dyt && nc < p.Nc) {
+                cf.k1 = *reinterpret_cast<const float4*>(p.dcoef + nc); cf.k2 = *reinterpret_cast<const float4*>(p.dcoef + p.Nc + nc);
+                cf.k3 = *reinterpret_cast<const float4*>(p.dcoef + 2 * p.Nc + nc);
+            }
+        }
+        WMeta meta[RS];
+        issue_raw<BM, BN>(p, g.zeros, tdd, tdh, tdw, raw[0], meta[0], st, meu, two_x, two_dy, wave, lane);
+        if constexpr (STAGES == 3) issue_raw<BM, BN>(p, g.zeros, tdd, tdh, tdw, raw[1], meta[1], st, meu, two_x, two_dy, wave, lane);
+        wait_vmcnt<0>();                    // own chunks only: no barrier needed before reading them back
+        {
+            WXIn<BM, BN> xin;
+            raw_load<BM, BN>(raw[0], xin, two_x, two_dy, wave, lane);
+            transform_store<BM, BN>(xin, meta[0], cf, p.xt, p.dyt, As, Bs, wave, lane);
+        }
+        issue_raw<BM, BN>(p, g.zeros, tdd, tdh, tdw, raw[0], meta[0], st, meu, two_x, two_dy, wave, lane);
+        // step s consumes ring slot s % 2, transforms raw slot (s + 1) % (S - 1) into ring slot (s + 1) % 2 and re-targets it
         for (int base = 0; base < nsteps; base += 2) {
-            pipe_step<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S1, S0, acc, cf, bsum, do_bias, left, st, meu, two_x, two_dy, wave, lane, wm, wn);
-            left -= BKM;
-            if (base + 1 < nsteps) { pipe_step<BM, BN, FUSED>(p, g.zeros, apad, tdd, tdh, tdw, S0, S1, acc, cf, bsum, do_bias, left, st, meu, two_x, two_dy, wave, lane, wm, wn); left -= BKM; }
+            pipe_step_fused<BM, BN>(p, g.zeros, tdd, tdh, tdw, raw[1 % RS], meta[1 % RS], cf, As + A_STAGE, Bs + B_STAGE, As, Bs, acc, bsum,
+                                    do_bias, st, meu, two_x, two_dy, wave, lane, wm, wn);
+            if (base + 1 < nsteps)
+                pipe_step_fused<BM, BN>(p, g.zeros, tdd, tdh, tdw, raw[0], meta[0], cf, As, Bs, As + A_STAGE, Bs + B_STAGE, acc, bsum,
+                                        do_bias, st, meu, two_x, two_dy, wave, lane, wm, wn);
         }
     }
 
@@ -603,7 +682,7 @@ bool wgrad_ok(const WgradArgs& a) {
     if (a.ntaps > P3D_MAX_TAPS || !a.zeros) return false;
     if ((a.K & 3) || (a.ldx & 3) || (a.Nc & 3) || (a.ldy & 3)) return false;
     if (a.pair && a.K > 32) return false;
-    if (a.xt < 0 || a.xt > 2 || (a.xt && (a.pair || !a.nans || !a.xs1 || !a.xt1))) return false;
+    if (a.xt < 0 || a.xt > 2 || (a.xt && (a.pair || !a.xs1 || !a.xt1))) return false;
     if (a.xt == 2 && (!a.x2 || !a.xs2 || !a.xt2 || (a.ldx2 & 3))) return false;
     if (a.dyt && (!a.dy2 || !a.dcoef || (a.ldy2 & 3) || a.pair)) return false;
     for (int t = 0; t < a.ntaps; ++t)
@@ -682,7 +761,7 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
     g.nprob = (int)live.size();
     g.zeros = live[0]->zeros;
     bool fused = false;
-    for (auto* a : live) { if (a->xt || a->dyt) fused = true; if (a->nans) g.nans = a->nans; }
+    for (auto* a : live) if (a->xt || a->dyt) fused = true;
     const WPlan solo = live.size() == 1 ? plan(*live[0]) : WPlan{64, 64, 0, 1, 0.0};
     const int tm = solo.tm, tn = solo.tn;
     long long tiles64_all = 0;

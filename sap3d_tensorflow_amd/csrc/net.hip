@@ -128,6 +128,7 @@ struct Ctx {
     bool update_moving = false;
     bool per_sample = false;          // batch-statistics BNs normalise every clip by its own statistics (p3d_predict_windows)
     bool fuse = false;                // BatchNorm fused into the neighbouring convs' operand paths (set by run_forward / run_backward)
+    bool fuse_bwd = false;            // ... in the backward pass as well (else: BatchNorm's backward keeps its own launches)
     hipStream_t s = nullptr;
     Prof* prof = nullptr;
     hipStream_t side = nullptr;       // weight gradients run here, off the backward critical path
@@ -158,7 +159,6 @@ void launch(const Ctx& c, const char* kernel, double flops, double bytes, F&& f)
 }
 
 const float* g_zero_page = nullptr;      // 1 KiB of zeros (device), set by p3d_create / op entry points
-const float* g_nan_page = nullptr;       // 1 KiB of quiet NaNs: padded rows of relu-transformed operands (conv_igemm2.hip)
 
 void igemm_work(const IgemmArgs& a, double& flops, double& bytes) {
     const double M = (double)a.N * a.Gd * a.Gh * a.Gw;
@@ -172,7 +172,7 @@ void launch_igemm(const Ctx& c, const IgemmArgs& a0, int allow_split = 0) {
     IgemmArgs a = a0;
     double fl, by;
     igemm_work(a, fl, by);
-    a.zeros = g_zero_page; a.nans = g_nan_page;
+    a.zeros = g_zero_page;
     const P3dIgemmPlan pl = p3d_igemm2_plan(a, allow_split);
     const char* name = pl.name;
     if (a.f16) name = pl.bm == 128 ? (pl.bn == 128 ? "igemm2_kernel<128,128,f16>" : "igemm2_kernel<128,64,f16>") : "igemm2_kernel<64,64,f16>";
@@ -269,7 +269,7 @@ void launch_wgrad(const Ctx& c, const WgradArgs& a0) {
     const double side = (double)a.N * a.Di * a.Hi * a.Wi;
     const double fl = 2.0 * M * a.ntaps * (double)a.K * a.Nc;
     const double by = 4.0 * (std::min(M * a.ntaps, side) * a.K + M * a.Nc + (double)a.ntaps * a.K * a.Nc);
-    a.zeros = g_zero_page; a.nans = g_nan_page;
+    a.zeros = g_zero_page;
     launch(c, p3d_wgrad2_variant(a), fl, by, [&]() { return p3d_launch_wgrad2(a, c.s); });
 }
 
@@ -485,11 +485,9 @@ void ensure_zero_page() {
     // one page per process; igemm2 reads it for padded rows and channel tails
     if (g_zero_page) return;
     float* p = nullptr;
-    HIPCHECK(hipMalloc((void**)&p, 2048));
+    HIPCHECK(hipMalloc((void**)&p, 1024));
     HIPCHECK(hipMemset(p, 0, 1024));
-    std::vector<uint32_t> nan(256, 0x7fc00000u);
-    HIPCHECK(hipMemcpy(p + 256, nan.data(), 1024, hipMemcpyHostToDevice));
-    g_zero_page = p; g_nan_page = p + 256;
+    g_zero_page = p;
 }
 }  // namespace
 
@@ -688,7 +686,7 @@ struct p3d_handle {
     void queue_wgrad(const Ctx& c, const WgradArgs& a0) {
         if (c.dry) return;
         WgradArgs a = a0;
-        a.zeros = g_zero_page; a.nans = g_nan_page;
+        a.zeros = g_zero_page;
         const double M = (double)a.N * a.Gd * a.Gh * a.Gw;
         const double side = (double)a.N * a.Di * a.Hi * a.Wi;
         PendingWgrad pw;
@@ -735,7 +733,11 @@ struct p3d_handle {
     // reduce, the next input-gradient / filter-gradient launch applies BatchNorm's backward on its operand path.  The
     // unfused ops stay in the graph (per-sample inference statistics, p3d_set_bn_fusion(h, 0), parity tests of one
     // path against the other) and run instead when Ctx::fuse is off.
-    bool fuse_bn = true;
+    // OFF by default: measured on MI355X at 8 clips of 16x112x112 (profiles/r03_bn_fusion_ab.json) the fused forward is a wash
+    // (17.42-17.52 vs 17.33-17.36 ms / step, 96 launches fewer) and the fully fused step is slower (18.4-18.5 ms, 192 fewer):
+    // with one wave per SIMD nothing hides the operand work, so it costs about what the removed launches did.
+    bool fuse_bn = false;
+    bool fuse_bn_bwd = false;         // p3d_set_bn_fusion(h, 2): the backward pass fused too
     bool last_forward_fused = false;
     // Only bottlenecks whose inner tensors have at most this many rows are built fusable: there a BatchNorm pass is a
     // latency-bound launch of its own (stage 3 at 8 clips of 16x112x112: 784 rows), while on big tensors the passes stream at
@@ -894,8 +896,18 @@ struct p3d_handle {
             else fwd_body(c);
         };
         op.bwd = [=](const Ctx& c) {
-            if (!(c.fuse && cf.any())) {
-                queue_wgrad(c, wgrad_conv(g, x->N, x->p, x->ld, Cin, y->g, y->ld, Cout, w->g, bias ? bias->g : nullptr, stem));
+            if (!(c.fuse_bwd && cf.any())) {
+                // BatchNorm's backward as launches of its own.  After a FUSED forward the normalised input was never stored:
+                // the filter gradient reads it as relu(scale*y + shift) on its operand path (scale / shift published by the forward)
+                const bool fin = c.fuse && cf.at != 0;
+                WgradArgs wa = wgrad_conv(g, x->N, (fin ? cf.src[0].y : x)->p, (fin ? cf.src[0].y : x)->ld, Cin, y->g, y->ld, Cout, w->g,
+                                          bias ? bias->g : nullptr, stem);
+                if (fin) {
+                    wa.xt = cf.at == P3D_AT_RELU2 ? 2 : 1;
+                    wa.xs1 = cf.src[0].bn->scale; wa.xt1 = cf.src[0].bn->shift;
+                    if (wa.xt == 2) { wa.x2 = cf.src[1].y->p; wa.ldx2 = cf.src[1].y->ld; wa.xs2 = cf.src[1].bn->scale; wa.xt2 = cf.src[1].bn->shift; }
+                }
+                queue_wgrad(c, wa);
                 if (xflag) {
                     const int accum = *xflag;
                     auto v = igemm_conv_input_side(g, x->N, y->g, y->ld, Cout, x->g, x->ld, Cin, w->p, nullptr, accum,
@@ -945,7 +957,7 @@ struct p3d_handle {
                     a.ngate = cf.ngate; a.raw_store = cf.raw ? 1 : 0;
                     for (int q = 0; q < cf.ngate; ++q) a.gate[q] = bn_gate(cf.gate[q]);
                     if (!c.dry) {
-                        IgemmArgs t = a; t.zeros = g_zero_page; t.nans = g_nan_page;
+                        IgemmArgs t = a; t.zeros = g_zero_page;
                         const int mt = p3d_igemm2_mtiles(t, p3d_igemm2_plan(t, 1));
                         for (int q = 0; q < cf.ngate; ++q) {
                             if (mt > cf.gate[q].bn->gpart_cap) throw P3dError("gradient partials overflow their arena slot");
@@ -1151,7 +1163,7 @@ struct p3d_handle {
             launch(c, kn_apply.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_apply(a, c.s); });
         };
         op.bwd = [=](const Ctx& c) {
-            if (fused_site && c.fuse) return;
+            if (fused_site && c.fuse_bwd) return;
             if (small) {
                 BnSmallArgs sa = small_args(c);
                 sa.batch1 = bn1->used_batch; sa.batch2 = two ? bn2->used_batch : 0;
@@ -2073,13 +2085,14 @@ struct p3d_handle {
     void tune_plans() {
         Ctx c; c.training = true; c.s = stream;
         const bool want = fuse_bn;
-        for (int mode = 0; mode < 2; ++mode) {      // both launch lists: BatchNorm fusion can be switched per handle later
-            fuse_bn = mode == 1;
+        const bool want_bwd = fuse_bn_bwd;
+        for (int mode = 0; mode < 3; ++mode) {      // every launch list: BatchNorm fusion can be switched per handle later
+            fuse_bn = mode >= 1; fuse_bn_bwd = mode == 2;
             run_forward(c);
             run_loss(c);
             run_backward(c, false);
         }
-        fuse_bn = want;
+        fuse_bn = want; fuse_bn_bwd = want_bwd;
         HIPCHECK(hipStreamSynchronize(c.s));
         HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
         HIPCHECK(hipStreamSynchronize(c.s));
@@ -2155,6 +2168,7 @@ struct p3d_handle {
     bool run_backward(const Ctx& c0, bool allreduce, bool with_adam = false) {
         Ctx c = c0; c.z0 = zb; c.z1 = zb + zb_bytes;
         c.fuse = last_forward_fused && !c.dry;       // the backward follows the forward that produced the activations
+        c.fuse_bwd = c.fuse && fuse_bn_bwd;
         bool adam_done = false;
         static const bool no_side = getenv("P3D_NO_SIDE_STREAM") != nullptr;
         c.side = (c.prof || no_side) ? nullptr : side_stream;      // per-launch profiling keeps one stream
@@ -2641,6 +2655,7 @@ int p3d_set_bn_fusion(p3d_handle* h, int enable) {
     API_BEGIN
     if (!h) throw P3dError("null handle");
     h->fuse_bn = enable != 0;
+    h->fuse_bn_bwd = enable >= 2;
     h->drop_step_graph();
     API_END
 }
@@ -3184,7 +3199,7 @@ int p3d_shutdown(void) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return 0;
     hipDeviceSynchronize();
     p3d_release_scratch();
-    if (g_zero_page) { hipFree((void*)g_zero_page); g_zero_page = nullptr; g_nan_page = nullptr; }
+    if (g_zero_page) { hipFree((void*)g_zero_page); g_zero_page = nullptr; }
     API_END
 }
 

@@ -93,7 +93,6 @@ struct IgemmArgs {
     const float* x2; int ldx2;
     BnFold f1, f2;        // RELU1 / RELU2: the BatchNorms of x and x2
     BnGradFold gf;        // GRAD
-    const float* nans;    // >= 128 B of quiet NaNs: what padded rows of a RELU-transformed operand read (relu(NaN) = 0: maxNum)
     // gated epilogue (input gradients through a fused BatchNorm + ReLU): the value v of every output element
     // (after bias / accumulate) goes raw to y when raw_store, and gated to gate[q].out; ngate = 0: plain store to y
     int ngate, raw_store;
@@ -139,7 +138,6 @@ struct WgradArgs {
     int dyt;              // dense operand: 0 plain, 1 dcoef[0][n]*dy + dcoef[1][n]*dy2 + dcoef[2][n]
     const float* dy2; int ldy2;
     const float* dcoef;   // [3][Nc]
-    const float* nans;    // NaN page (needed when xt != 0)
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
 };

@@ -168,7 +168,7 @@ class P3DSession:
 
     def set_bn_fusion(self, enable=True):
         """BatchNorm + ReLU between the convs of a bottleneck on the convs' operand paths (default) or as passes of their own."""
-        check(lib().p3d_set_bn_fusion(self._h, int(bool(enable))))
+        check(lib().p3d_set_bn_fusion(self._h, int(enable)))      # 0 off, 1 forward, 2 forward + backward
 
     def predict_windows(self, x):
         """B windows of gen_pred.py:100-168 at once: row k equals forward(x[k:k+1], training=False) of a batch-1

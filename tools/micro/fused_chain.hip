@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
             a.x = x; a.N = s.N; a.Di = s.D; a.Hi = s.H; a.Wi = s.W; a.ldx = s.K; a.K = s.K;
             a.Gd = s.D; a.Gh = s.H; a.Gw = s.W; a.isd = a.ish = a.isw = 1;
             a.y = y; a.Do = s.D; a.Ho = s.H; a.Wo = s.W; a.ldy = s.Nc; a.Nc = s.Nc; a.osd = a.osh = a.osw = 1;
-            a.w = w; a.wT = s.wT; a.zeros = pages; a.nans = pages + 256;
+            a.w = w; a.wT = s.wT; a.zeros = pages;
             int t = 0;
             for (int kd = 0; kd < s.kd; ++kd) for (int kh = 0; kh < s.kh; ++kh) for (int kw = 0; kw < s.kw; ++kw) {
                 a.taps[t].dd = (int16_t)(kd - (s.kd - 1) / 2); a.taps[t].dh = (int16_t)(kh - (s.kh - 1) / 2); a.taps[t].dw = (int16_t)(kw - (s.kw - 1) / 2);
@@ -90,7 +90,6 @@ int main(int argc, char** argv) {
         if (!s.wT) {
             { IgemmArgs a = base(); a.statpart = statpart; vs.push_back({"plain + stats epilogue", a}); }
             { IgemmArgs a = base(); a.statpart = statpart; a.at_mode = P3D_AT_RELU1; a.f1 = fold(false, 0); vs.push_back({"relu1 (published table) + stats", a}); }
-            { IgemmArgs a = base(); a.statpart = statpart; a.at_mode = P3D_AT_RELU1; a.f1 = fold(false, 0); a.nans = pages; vs.push_back({"relu1 (published) + stats, zero page for pads [WRONG RESULTS, timing]", a}); }
             if (np) { IgemmArgs a = base(); a.statpart = statpart; a.at_mode = P3D_AT_RELU1; a.f1 = fold(true, np); vs.push_back({"relu1 (folds partials) + stats", a}); }
             { IgemmArgs a = base(); a.statpart = statpart; a.at_mode = P3D_AT_RELU2; a.x2 = x2; a.ldx2 = s.K; a.f1 = fold(false, 0); a.f2 = fold(false, 0); vs.push_back({"relu2 (published) + stats", a}); }
         } else {
