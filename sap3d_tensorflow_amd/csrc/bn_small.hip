@@ -210,7 +210,7 @@ bool p3d_bn_small_ok(long M, int C) { return M <= 1024 && (C % CB) == 0; }
 // wide tensors get 16-channel slabs (64-byte row segments), narrow ones 8-channel slabs (more blocks)
 static hipError_t dispatch(const BnSmallArgs& a, bool bwd, hipStream_t s) {
     if (!p3d_bn_small_ok(a.M, a.C)) return hipErrorInvalidValue;
-    static const int forced = getenv("P3D_BN_CB") ? atoi(getenv("P3D_BN_CB")) : 0;       // tuning: 4, 8 or 16 channels per block
+    static const int forced = p3d_tune_env("P3D_BN_CB") ? atoi(p3d_tune_env("P3D_BN_CB")) : 0;       // tuning: 4, 8 or 16 channels per block
     if (forced == 4) return launch_small<4>(a, bwd, s);
     if (forced == 8) return launch_small<8>(a, bwd, s);
     if (forced == 16 && a.C % 16 == 0) return launch_small<16>(a, bwd, s);

@@ -600,12 +600,10 @@ struct WTune { long lds_kb = P3D_WGRAD64_LDS_KB; int slots = 0; bool no_rect = f
 const WTune& wtune() {
     static const WTune t = [] {
         WTune w;
-#if defined(P3D_TUNING)
-        if (const char* e = getenv("P3D_WGRAD_LDS_KB")) { const long v = atol(e); if (v > 0 && v <= 160) w.lds_kb = v; }
-        if (const char* e = getenv("P3D_WGRAD_SLOTS")) w.slots = atoi(e);
-        if (getenv("P3D_WGRAD_NO_RECT")) w.no_rect = true;
-        if (const char* e = getenv("P3D_WGRAD_POLITE_ROWS")) w.polite_rows = atoll(e);
-#endif
+        if (const char* e = p3d_tune_env("P3D_WGRAD_LDS_KB")) { const long v = atol(e); if (v > 0 && v <= 160) w.lds_kb = v; }
+        if (const char* e = p3d_tune_env("P3D_WGRAD_SLOTS")) w.slots = atoi(e);
+        if (p3d_tune_env("P3D_WGRAD_NO_RECT")) w.no_rect = true;
+        if (const char* e = p3d_tune_env("P3D_WGRAD_POLITE_ROWS")) w.polite_rows = atoll(e);
         return w;
     }();
     return t;

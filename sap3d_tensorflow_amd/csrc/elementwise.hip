@@ -639,7 +639,7 @@ hipError_t p3d_bn_apply(const BnApplyArgs& a, hipStream_t s) {
 }
 
 bool p3d_bn_fold_apply_ok(long M, int C, int nparts1, int nparts2, float drop_scale) {
-    static const bool off = getenv("P3D_BN_FOLD_APPLY") && atoi(getenv("P3D_BN_FOLD_APPLY")) == 0;      // A/B runs
+    static const bool off = p3d_tune_env("P3D_BN_FOLD_APPLY") && atoi(p3d_tune_env("P3D_BN_FOLD_APPLY")) == 0;      // A/B runs
     return !off && (C % 64) == 0 && nparts1 <= 128 && nparts2 <= 128 && M >= 1024 && !(drop_scale > 0.f);
 }
 hipError_t p3d_bn_fold_apply(const BnApplyArgs& a, const BnParams& bn1, const BnParams& bn2, int batch1, int batch2, int update_moving,

@@ -5,7 +5,8 @@
 //    one shape only: the reference's resize branch (skimage) is not on the path the trainers take.  Arithmetic is
 //    float64 on float32 inputs.  One 256-thread block per map; every reduction folds in a fixed order, counts use
 //    integer atomics: results are bit-reproducible.
-//  * mapf (dataflow.py:187-216): decoded BGR uint8 frame -> RGB, minus the channel means, bilinear resize
+//  * mapf (dataflow.py:187-216): decoded BGR uint8 frame -> RGB, minus the channel means, bilinear resize (float32 path;
+//    the grey density maps go through OpenCV's uint8 fixed-point path, mapf_density_kernel)
 //    (cv2.INTER_LINEAR, what tensorpack's imgaug.Resize uses) to the clip size, / 255 -- one pass, written straight into
 //    the NDHWC clip buffer; and the grey-level density map -> resize -> / 255.
 #include "p3d_kernels.h"
@@ -310,6 +311,47 @@ __global__ __launch_bounds__(TPB) void mapf_kernel(const unsigned char* src, int
     }
 }
 
+// The grey density maps are resized as uint8 images (dataflow.py:210-214: cv2.imread(GRAYSCALE) -> Resize -> / 255.), i.e.
+// through OpenCV's fixed-point INTER_LINEAR (resize.cpp, HResizeLinear / VResizeLinear<uchar, int, short>): 11-bit weights
+// cvRound(w * 2048), int32 horizontal pass, vertical pass uchar((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2).
+// The horizontal tables zero the weight at a clamped border, the vertical pass clips the row indices and keeps the weights.
+__device__ __forceinline__ void lin_coef_u8(int d, double scale, int extent, bool clamp_weight, int& s0, int& s1, int& w0, int& w1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(f);
+    f -= (float)sx;
+    if (clamp_weight) {
+        if (sx < 0) { sx = 0; f = 0.f; }
+        if (sx >= extent - 1) { sx = extent - 1; f = 0.f; }
+    }
+    w0 = __float2int_rn(__fmul_rn(1.f - f, 2048.f));      // saturate_cast<short>(cvRound(.)): round half to even
+    w1 = __float2int_rn(__fmul_rn(f, 2048.f));
+    s0 = min(max(sx, 0), extent - 1); s1 = min(max(sx + 1, 0), extent - 1);
+}
+__global__ __launch_bounds__(TPB) void mapf_density_kernel(const unsigned char* src, int n_frames, int H0, int W0, float* dst, int H, int W) {
+    const double sx = (double)W0 / W, sy = (double)H0 / H;
+    const bool same = H0 == H && W0 == W;                 // cv::resize copies when the sizes agree
+    const long long total = (long long)n_frames * H * W;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const long long fr = i / ((long long)W * H);
+        const unsigned char* f0 = src + (size_t)fr * H0 * W0;
+        int v;
+        if (same) {
+            v = f0[(size_t)y * W0 + x];
+        } else {
+            int x0, x1, a0, a1, y0, y1, b0, b1;
+            lin_coef_u8(x, sx, W0, true, x0, x1, a0, a1);
+            lin_coef_u8(y, sy, H0, false, y0, y1, b0, b1);
+            const int r0 = (int)f0[(size_t)y0 * W0 + x0] * a0 + (int)f0[(size_t)y0 * W0 + x1] * a1;
+            const int r1 = (int)f0[(size_t)y1 * W0 + x0] * a0 + (int)f0[(size_t)y1 * W0 + x1] * a1;
+            v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+        }
+        dst[i] = (float)((double)v / 255.0);              // numpy: uint8 / 255. is float64, then fed as float32
+    }
+}
+
 }  // namespace
 
 hipError_t p3d_metric_cc(const float* a, const float* b, int n_maps, int n_pix, double* out, hipStream_t s) {
@@ -350,6 +392,6 @@ hipError_t p3d_mapf_frames(const unsigned char* bgr, int n_frames, int H0, int W
 hipError_t p3d_mapf_density(const unsigned char* grey, int n_frames, int H0, int W0, float* dst, int H, int W, hipStream_t s) {
     const long long total = (long long)n_frames * H * W;
     const unsigned grid = (unsigned)((total + TPB - 1) / TPB > 65535 ? 65535 : (total + TPB - 1) / TPB);
-    hipLaunchKernelGGL(mapf_kernel<1>, dim3(grid), dim3(TPB), 0, s, grey, n_frames, H0, W0, dst, H, W, 0.f, 0.f, 0.f, 0);
+    hipLaunchKernelGGL(mapf_density_kernel, dim3(grid), dim3(TPB), 0, s, grey, n_frames, H0, W0, dst, H, W);
     return hipGetLastError();
 }

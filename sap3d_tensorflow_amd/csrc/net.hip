@@ -28,6 +28,22 @@ namespace {
 
 thread_local std::string g_err;
 
+// The product's own runtime switches (everything else is a -DP3D_TUNING switch, p3d_tune_env): read once.
+struct RuntimeEnv { bool debug_sync = false, graph = false, no_side_stream = false; };
+const RuntimeEnv& runtime_env() {
+    static const RuntimeEnv env = [] {
+        RuntimeEnv e;
+        e.debug_sync = getenv("P3D_DEBUG_SYNC") != nullptr;                                   // synchronise and log after every op
+        if (const char* v = getenv("P3D_GRAPH")) e.graph = atoi(v) != 0 && !e.debug_sync;      // captured step graph (slower on ROCm 7.2)
+        e.no_side_stream = getenv("P3D_NO_SIDE_STREAM") != nullptr;                            // everything on one stream
+        return e;
+    }();
+    return env;
+}
+// all-reduce bucket size in MB (also fixes where queued filter gradients are flushed); read whenever a handle or a communicator
+// is created, so that one process can build handles with different bucket sizes (tests/test_gpu_dp.py); 0: the default
+long bucket_mb_env() { const char* e = getenv("P3D_BUCKET_MB"); return e ? atol(e) : 0; }
+
 struct P3dError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
@@ -241,7 +257,7 @@ void on_side_stream(const Ctx& c, hipEvent_t ev, F&& f) {
     // timing diagnostic (WRONG RESULTS): P3D_TUNE_SKIP_SIDE=deconv,block1 drops the side-stream jobs queued during the backward of
     // ops whose name contains one of the substrings -- what that share of the filter gradients costs the step
     static const char* skip = [] {
-        const char* e = getenv("P3D_TUNE_SKIP_SIDE");
+        const char* e = p3d_tune_env("P3D_TUNE_SKIP_SIDE");
         if (e) fprintf(stderr, "[p3d] P3D_TUNE_SKIP_SIDE=%s: filter gradients are being DROPPED -- timing diagnostic, every result of this process is wrong\n", e);
         return e;
     }();
@@ -693,14 +709,14 @@ struct p3d_handle {
         pw.a = a; pw.op = c.prof ? c.prof->cur_op : std::string();
         pw.flops = 2.0 * M * a.ntaps * (double)a.K * a.Nc;
         pw.bytes = 4.0 * (std::min(M * a.ntaps, side) * a.K + M * a.Nc + (double)a.ntaps * a.K * a.Nc);
-        static const bool no_group = getenv("P3D_NO_WGRAD_GROUP") != nullptr;
-        static const int64_t flush_tiles = getenv("P3D_WGRAD_FLUSH_TILES") ? atol(getenv("P3D_WGRAD_FLUSH_TILES")) : 512;   // tuning: 256 -> 17.25 ms / step, 512 -> 17.0, 1024 with groups of 12 -> 17.1
+        static const bool no_group = p3d_tune_env("P3D_NO_WGRAD_GROUP") != nullptr;
+        static const int64_t flush_tiles = p3d_tune_env("P3D_WGRAD_FLUSH_TILES") ? atol(p3d_tune_env("P3D_WGRAD_FLUSH_TILES")) : 512;   // tuning: 256 -> 17.25 ms / step, 512 -> 17.0, 1024 with groups of 12 -> 17.1
         const bool alone = no_group || wgrad_tiles64(a) >= 256;      // fills the chip by itself (and may take 128x128 tiles)
         if (alone) flush_wgrads(c);
         wq.push_back(pw);
         int64_t tiles = 0;
         for (auto& q : wq) tiles += wgrad_tiles64(q.a);
-        static const int group_max = getenv("P3D_WGRAD_GROUP_MAX") ? std::max(1, std::min(P3D_WGRAD_GROUP, atoi(getenv("P3D_WGRAD_GROUP_MAX")))) : P3D_WGRAD_GROUP;
+        static const int group_max = p3d_tune_env("P3D_WGRAD_GROUP_MAX") ? std::max(1, std::min(P3D_WGRAD_GROUP, atoi(p3d_tune_env("P3D_WGRAD_GROUP_MAX")))) : P3D_WGRAD_GROUP;
         if (alone || (int)wq.size() >= group_max || tiles >= flush_tiles) flush_wgrads(c);
     }
     void flush_wgrads(const Ctx& c) {
@@ -1303,7 +1319,7 @@ struct p3d_handle {
             return a;
         };
         // small tensors (every GroupNorm of stage 3): one launch each way, see gn.hip
-        static const bool no_small = getenv("P3D_NO_GN_SMALL") != nullptr;
+        static const bool no_small = p3d_tune_env("P3D_NO_GN_SMALL") != nullptr;
         const bool small = !no_small && !dropout && p3d_gn_small_ok(R, C, g1->G) && (!g2 || g2->G == g1->G);
         const std::string ksf = "gn_small_fwd_kernel<" + std::to_string(mode) + ">";
         const std::string ksb = "gn_small_bwd_kernel<" + std::to_string(mode) + ">";
@@ -2135,8 +2151,7 @@ struct p3d_handle {
     // ---- execution -------------------------------------------------------------------------------
     // P3D_DEBUG_SYNC=1: synchronise and log after every op (fault isolation, not for timing)
     void debug_sync(const char* dir, const Op& op, const Ctx& c) {
-        static const bool on = getenv("P3D_DEBUG_SYNC") != nullptr;
-        if (!on) return;
+        if (!runtime_env().debug_sync) return;
         fprintf(stderr, "[p3d] %s %s (%s) ...", dir, op.name.c_str(), op.kind.c_str());
         fflush(stderr);
         HIPCHECK(hipStreamSynchronize(c.s));
@@ -2149,7 +2164,7 @@ struct p3d_handle {
         Ctx cz = c; cz.z0 = zf; cz.z1 = zf + zf_bytes;
         cz.fuse = fuse_bn && !c.per_sample && !c.dry;
         last_forward_fused = cz.fuse;
-        static const bool no_side_f = getenv("P3D_NO_SIDE_STREAM") != nullptr;
+        const bool no_side_f = runtime_env().no_side_stream;
         cz.side = (c.prof || no_side_f || c.dry) ? nullptr : side_stream;      // ST_B sibling convs overlap
         const Ctx& c2 = cz;
         for (auto& op : ops) {
@@ -2170,7 +2185,7 @@ struct p3d_handle {
         c.fuse = last_forward_fused && !c.dry;       // the backward follows the forward that produced the activations
         c.fuse_bwd = c.fuse && fuse_bn_bwd;
         bool adam_done = false;
-        static const bool no_side = getenv("P3D_NO_SIDE_STREAM") != nullptr;
+        const bool no_side = runtime_env().no_side_stream;
         c.side = (c.prof || no_side) ? nullptr : side_stream;      // per-launch profiling keeps one stream
         if (zb_bytes) HIPCHECK(hipMemsetAsync(zb, 0, zb_bytes, c.s));
         HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
@@ -2186,7 +2201,7 @@ struct p3d_handle {
         // encoder (unet++, the GN nets) parks its first jobs only, and nothing is parked when the encoder's own launches fill
         // the chip (32x224x224 clips).
         std::vector<std::pair<hipEvent_t, std::function<void(const Ctx&)>>> parked;
-        static const bool no_defer = getenv("P3D_DEFER_SIDE") && atoi(getenv("P3D_DEFER_SIDE")) == 0;
+        static const bool no_defer = p3d_tune_env("P3D_DEFER_SIDE") && atoi(p3d_tune_env("P3D_DEFER_SIDE")) == 0;
         const bool defer_on = c.side && !no_defer && defer_release_op > 0 && defer_budget > 0;
         parked_flops = 0;
         auto release_parked = [&]() {
@@ -2208,7 +2223,7 @@ struct p3d_handle {
                     if (reduce) reduce_range(adam_split, hi, c, 1);
                     hi = adam_split;
                 }
-                static const bool no_split = getenv("P3D_SPLIT_ADAM") && atoi(getenv("P3D_SPLIT_ADAM")) == 0;     // A/B runs
+                static const bool no_split = p3d_tune_env("P3D_SPLIT_ADAM") && atoi(p3d_tune_env("P3D_SPLIT_ADAM")) == 0;     // A/B runs
                 if (with_adam && !no_split) {
                     HIPCHECK(hipEventRecord(ev_side_early, c.side));
                     HIPCHECK(hipStreamWaitEvent(c.s, ev_side_early, 0));
@@ -2249,7 +2264,7 @@ struct p3d_handle {
         }
         flush_wgrads(c);
         if (c.defer || !parked.empty()) release_parked();
-        static const bool tune_tail = getenv("P3D_TUNE_TAIL") != nullptr;   // diagnostic: how long the side stream outlasts the main one
+        static const bool tune_tail = p3d_tune_env("P3D_TUNE_TAIL") != nullptr;   // diagnostic: how long the side stream outlasts the main one
         static hipEvent_t tail_main = nullptr, tail_side = nullptr;
         if (tune_tail && c.side && !c.dry) {
             if (!tail_main) { HIPCHECK(hipEventCreate(&tail_main)); HIPCHECK(hipEventCreate(&tail_side)); }
@@ -2328,8 +2343,7 @@ struct p3d_handle {
         if (step_graph) { hipGraphDestroy(step_graph); step_graph = nullptr; }
     }
     bool graphs_enabled() {
-        static const bool on = getenv("P3D_GRAPH") != nullptr && atoi(getenv("P3D_GRAPH")) != 0 && getenv("P3D_DEBUG_SYNC") == nullptr;
-        return on && !graph_disabled;
+        return runtime_env().graph && !graph_disabled;
     }
     void capture_step_graph(float drop) {
         drop_step_graph();
@@ -2467,11 +2481,8 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         HIPCHECK(hipSetDevice(cfg->device));
         h = new p3d_handle();
         h->cfg = *cfg;
-        if (const char* e = getenv("P3D_BUCKET_MB")) {           // gradient bucket size (also fixes where filter gradients are flushed)
-            const long mb = atol(e);
-            if (mb >= 1) h->bucket_floats = (int64_t)mb * (1 << 18);
-        }
-        if (const char* e = getenv("P3D_FUSE_MAX_ROWS")) h->fuse_max_rows = atoll(e);      // A/B runs: which bottlenecks are built fusable
+        if (const long mb = bucket_mb_env(); mb >= 1) h->bucket_floats = (int64_t)mb * (1 << 18);
+        if (const char* e = p3d_tune_env("P3D_FUSE_MAX_ROWS")) h->fuse_max_rows = atoll(e);      // A/B runs: which bottlenecks are built fusable
         ensure_zero_page();
         {   // the main stream carries the dependent chain of small launches and the comm stream the all-reduces: both above
             // the side stream's filter gradients (measured: no effect on the step time on this ROCm, 17.98 vs 17.95 ms;
@@ -2888,10 +2899,7 @@ int p3d_comm_init(p3d_handle* h, const void* idbytes) {
     ncclUniqueId id;
     memcpy(&id, idbytes, sizeof(id));
     NCCLCHECK(ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
-    if (const char* e = getenv("P3D_BUCKET_MB")) {
-        const long mb = atol(e);
-        if (mb >= 1) h->bucket_floats = (int64_t)mb * (1 << 18);
-    }
+    if (const long mb = bucket_mb_env(); mb >= 1) h->bucket_floats = (int64_t)mb * (1 << 18);
     API_END
 }
 

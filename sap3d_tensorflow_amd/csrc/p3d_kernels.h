@@ -20,6 +20,18 @@
 #define P3D_STAT_REPLICAS 16   // lanes that share a channel's partial sums in the finalize kernels (fixed 4-step shuffle fold)
 #define P3D_FOLD_MAX 32        // fused BatchNorm: up to this many per-tile partials a consuming launch folds itself (else a finalize launch)
 
+// Tuning / diagnostic switches are environment variables only in a -DP3D_TUNING build (tools/*.sh pass it through
+// P3D_EXTRA_HIPCC_FLAGS); in the product build they are absent, so a stray variable cannot change results or drop work.
+#include <stdlib.h>
+inline const char* p3d_tune_env(const char* name) {
+#if defined(P3D_TUNING)
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 struct P3dTap {
     int16_t dd, dh, dw;   // gathered coordinate = g*is + d{d,h,w}
     int16_t widx;         // which [K][N] slab of the weight tensor

@@ -59,8 +59,13 @@ def test_buckets_tile_the_gradient_buffer_and_are_final(structure, cfg, shape, b
     s.close()
 
 
-@pytest.mark.parametrize("structure", ["unet", "unet++nonsa", "gn_p3d"])
-def test_single_rank_allreduce_is_identity(structure):
+# every structure with many small buckets, and the headline one with ONE bucket that swallows the whole buffer: then the
+# parked decoder jobs, the two-part optimiser step and the single hand-over all coincide at the last boundary
+IDENTITY = [(st, "1") for st in ("unet", "concat", "unet++nonsa", "unet++ds", "gn_p3d", "gn_p3d_concat", "gn_p3d_decoder")] + [("unet", "4096")]
+
+
+@pytest.mark.parametrize("structure,bucket_mb", IDENTITY)
+def test_single_rank_allreduce_is_identity(structure, bucket_mb, monkeypatch):
     import torch  # noqa: F401  (same process as libp3dhip, like bench.py at N > 1)
     from sap3d_tensorflow_amd import P3DSession
     cfg = p3d.NetConfig(base=16, blocks=(2, 2, 3)) if structure == "unet" else p3d.NetConfig(base=16, blocks=(1, 1, 2))
@@ -68,8 +73,8 @@ def test_single_rank_allreduce_is_identity(structure):
     x = p3d.synthetic_clip(0, shape + (3,))
     y = p3d.synthetic_target(3, shape)
 
-    os.environ["P3D_BUCKET_MB"] = "1"              # many small buckets; read at create (the bucket walk also fixes where the
-                                                   # queued filter gradients are flushed, so both runs must share it)
+    # read at create (the bucket walk also fixes where the queued filter gradients are flushed, so both runs must share it)
+    monkeypatch.setenv("P3D_BUCKET_MB", bucket_mb)
 
     def run(with_comm):
         s = P3DSession(structure, batch=shape[0], frames=shape[1], height=shape[2], width=shape[3], base=cfg.base,

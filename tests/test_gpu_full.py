@@ -1,7 +1,12 @@
 """Parity at the reference architecture (P3D-199, 16x112x112) -- BASELINE.json configs[0..2] --
 against the float32 oracle run on the GPU box's host cores."""
+import os
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import p3d
 
@@ -68,7 +73,9 @@ def test_config2_forward_backward(ref_params):
     Measured on this graph (199 layers, fp32, B=2): the float32 ORACLE's gradients sit 0.14 (median) / 0.21 (max)
     rel-L2 from the float64 oracle's -- ReLU / max-pool decisions flipping on 1e-7 perturbations make deep
     gradients chaotic in fp32 -- while the loss agrees to 3e-7 and the decoder gradients to 1e-3.  So the HIP
-    gradients are held to the float32 oracle's own distance from float64 (x1.5 + 2e-3), tensor by tensor."""
+    gradients are held to the float32 oracle's own distance from float64: median and maximum over the tensors within
+    x1.5 + 2e-3, and tensor by tensor the ratio e_hip / (e_o32 + 1e-3) within twice its measured maximum
+    (tests/gates.py: the two fp32 implementations flip different decisions, so single tensors differ by a factor)."""
     from sap3d_tensorflow_amd import P3DSession
     x = p3d.synthetic_clip(0, (2, 16, 112, 112, 3))
     y = p3d.synthetic_target(3, (2, 16, 112, 112))
@@ -92,18 +99,21 @@ def test_config2_forward_backward(ref_params):
           (np.median(list(e_hip.values())), max(e_hip.values()), np.median(list(e_o32.values())), max(e_o32.values()), worst[0]))
     assert np.median(list(e_hip.values())) <= 1.5 * np.median(list(e_o32.values())) + 2e-3, worst
     assert max(e_hip.values()) <= 1.5 * max(e_o32.values()) + 2e-3, worst
-    for n in e_hip:
-        assert e_hip[n] <= 2.5 * e_o32[n] + 2e-2, (n, e_hip[n], e_o32[n])
+    import gates
+    gates.check("config2/worst_ratio", worst[0][0], margin=2.0, floor=0.0, detail=worst)
+    for n in e_hip:      # and never beyond what a single flipped decision costs at this depth
+        assert e_hip[n] <= 3.0 * e_o32[n] + 1e-2, (n, e_hip[n], e_o32[n])
     s.close()
 
 
 @pytest.mark.parametrize("structure,shape,step,tol,first_group", [
     ("unet", (8, 16, 112, 112), 2e-5, 8e-2, 0),       # BASELINE.json configs[2]: batch 8, 16x112x112
     ("unet", (1, 32, 224, 224), 2e-5, 8e-2, 0),       # the clip shape of configs[4] (32 frames of 224x224), one clip
-    # configs[3] graph (GroupNorm + CBAM).  CBAM's arg-max routing bends the loss sooner, so half the step; and the
-    # stem + stage-1 group is left out: its gradient norm is 1.4e7 (loss 8e4), the loss is linear along it for less
-    # than 1e-5 L = 100 ulps of the fp32 loss, and run-to-run atomics noise alone is 20 % of that (measured).
-    ("gn_p3d", (2, 16, 112, 112), 1e-5, 15e-2, 1),
+    # configs[3] graph (GroupNorm + CBAM): CBAM's arg-max routing bends the loss sooner, so half the step.  All four groups
+    # (the kernels are bit-reproducible since round 2, so the stem + stage-1 group is measurable too), at two clips and at
+    # configs[3]'s per-GPU share of eight.
+    ("gn_p3d", (2, 16, 112, 112), 1e-5, 15e-2, 0),
+    ("gn_p3d", (8, 16, 112, 112), 1e-5, 15e-2, 0),
 ])
 def test_directional_derivative_at_full_size(structure, shape, step, tol, first_group):
     """Size-independent property, no oracle involved: moving the parameters by a small step delta must change the

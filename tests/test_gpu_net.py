@@ -5,21 +5,34 @@ tolerance, 1e-3 relative.  Gradients are judged against the fp32 noise floor mea
 fp32 and fp64 oracles (tests/test_oracle_vs_torch.py::test_small_net_fp32_matches_fp64 explains
 why two correct fp32 implementations differ by ~1e-2 there): the HIP gradient must be as close to
 the fp64 oracle as the fp32 oracle is, within a factor."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import p3d
 
 pytestmark = pytest.mark.gpu
 
 
-# Gradient tolerance of the small-net tests: 5x the float32 oracle's own rel-L2 distance from the float64 oracle,
-# + 2e-3, + FLIP.  FLIP pays for ReLU / max-pool / arg-max decisions that the HIP forward (1e-6 rms from float64, fp32
-# MFMA sums run sequentially along K) takes differently from the oracle: one flipped element in a layer of N moves
-# that layer's gradient by ~1/sqrt(N) (0.3 % at N = 131072) and every upstream gradient inherits it.  Which inputs
-# flip changes with any re-ordering of a sum (a new tile size is enough), so the allowance is uniform; a wrong
-# kernel shows as >= 1e-1, and the conv / deconv / pool kernels are held to 2e-5 at op level (test_gpu_ops.py).
-FLIP = 1.5e-2
+# Gradient tolerance of the small-net tests: 5x the float32 oracle's own rel-L2 distance from the float64 oracle + 2e-3
+# (the fp32 noise floor), plus -- per test case, not as a blanket -- what was MEASURED above that bound for the case
+# (tests/gates.py, tests/golden/measured_gates.json): a ReLU / max-pool / arg-max decision that the HIP forward (1e-6 rms
+# from float64, fp32 MFMA sums run sequentially along K) takes differently from the oracle moves that layer's gradient by
+# ~1/sqrt(N) and every upstream gradient inherits it; which inputs flip changes with any re-ordering of a sum, but for a
+# given build it is a fixed number (the kernels are bit-reproducible).  A wrong kernel shows as >= 1e-1, and the conv /
+# deconv / pool kernels are held to 2e-5 at op level (test_gpu_ops.py).
+from gates import grad_gate      # noqa: E402
+
+
+def grads_vs_oracles(s, g64, g32):
+    """rel-L2 errors of the session's gradients and of the float32 oracle's against the float64 oracle, per tensor."""
+    scale = np.median([np.linalg.norm(g) for g in g64.values()])
+    floor = 1e-2 * scale
+    return ({n: rel_l2(s.get_grad(n), w, floor) for n, w in g64.items()},
+            {n: rel_l2(g32[n], w, floor) for n, w in g64.items()})
 
 
 def randomise_norm_params(params, seed=5):
@@ -102,14 +115,7 @@ def test_backward_small(cfg, shape):
     loss, pred = s.backward(x, y, 0.0)
     assert abs(loss - l64) < 1e-5 * abs(l64)
     assert np.abs(pred - pr64).max() < 1e-4
-    scale = np.median([np.linalg.norm(g) for g in g64.values()])
-    worst = 0.0
-    for n, want in g64.items():
-        floor = 1e-2 * scale
-        e_hip = rel_l2(s.get_grad(n), want, floor)
-        e_o32 = rel_l2(g32[n], want, floor)
-        worst = max(worst, e_hip)
-        assert e_hip <= 5 * e_o32 + 2e-3 + FLIP, (n, e_hip, e_o32)
+    grad_gate("backward_small/base%d_%s" % (cfg.base, "x".join(map(str, shape))), *grads_vs_oracles(s, g64, g32))
     s.close()
 
 
@@ -173,10 +179,7 @@ def test_concat_head_forward_backward(cfg, shape):
     l32, _, g32, _ = p3d.loss_and_grads(dict(p32), x, y, 0.0, True, 'concat', cfg, np.float32)
     loss, pred = s.backward(x, y, 0.0)
     assert abs(loss - l64) < 1e-5 * abs(l64)
-    scale = np.median([np.linalg.norm(g) for g in g64.values()])
-    for n, want in g64.items():
-        floor = 1e-2 * scale
-        assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3 + FLIP, n
+    grad_gate("concat/base%d_%s" % (cfg.base, "x".join(map(str, shape))), *grads_vs_oracles(s, g64, g32))
     s.close()
 
 
@@ -209,10 +212,7 @@ def test_unetplusplus_nonsa_forward_backward(cfg, shape):
     loss, pred = s.backward(x, y, 0.0)
     assert abs(loss - l64) < 1e-5 * abs(l64)
     assert np.abs(pred - pr64).max() < 1e-4
-    scale = np.median([np.linalg.norm(g) for g in g64.values()])
-    for n, want in g64.items():
-        floor = 1e-2 * scale
-        assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3 + FLIP, n
+    grad_gate("unetpp_nonsa/base%d_%s" % (cfg.base, "x".join(map(str, shape))), *grads_vs_oracles(s, g64, g32))
     s.close()
 
 
@@ -236,10 +236,7 @@ def test_unetplusplus_nonsa_dropout_and_train_steps():
     _, _, g32, _ = p3d.loss_and_grads(dict(p32), x, y, 0.5, True, st, cfg, np.float32, keep_mask=keep.astype(np.float32))
     assert abs(loss - l64) < 1e-5 * abs(l64)
     assert np.abs(pred - pr64).max() < 1e-4
-    scale = np.median([np.linalg.norm(g) for g in g64.values()])
-    for n, want in g64.items():
-        floor = 1e-2 * scale
-        assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3 + FLIP, n
+    grad_gate("unetpp_nonsa_dropout", *grads_vs_oracles(s, g64, g32))
     # Adam + moving statistics
     # (Adam's first updates are +-lr * sign(g), so fp32 rounding of near-zero gradients moves weights by O(lr):
     # the fp32 oracle itself drifts 5e-4 from the fp64 one by the third loss; judge against that drift.)
@@ -298,8 +295,7 @@ def test_unetplusplus_ds_self_attention(cfg, shape):
     assert np.abs(pred - pr64).max() < 3e-4
     scale = np.median([np.linalg.norm(g) for g in g64.values()])
     floor = 1e-2 * scale
-    for n, want in g64.items():
-        assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3 + FLIP, n
+    grad_gate("unetpp_ds/base%d_%s" % (cfg.base, "x".join(map(str, shape))), *grads_vs_oracles(s, g64, g32))
     # dropout 0.5 sits on the output of the last attention block (p3d.py:388): read the keep pattern back.  Dropping
     # half of the head's inputs doubles the weight of a flipped element, hence the wider gradient allowance.
     s.forward(x, 0.0, True)
@@ -314,10 +310,7 @@ def test_unetplusplus_ds_self_attention(cfg, shape):
     loss, pred = s.backward(x, y, dropout=0.5, seed=11)
     assert abs(loss - l64) < 1e-5 * abs(l64)
     assert np.abs(pred - pr64).max() < 3e-4
-    scale = np.median([np.linalg.norm(g) for g in g64.values()])
-    floor = 1e-2 * scale
-    for n, want in g64.items():
-        assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3 + 5e-2, n
+    grad_gate("unetpp_ds_dropout/base%d_%s" % (cfg.base, "x".join(map(str, shape))), *grads_vs_oracles(s, g64, g32))
     s.close()
 
 
@@ -341,11 +334,11 @@ def _gn_params(cfg, dtype, head='p3d'):
 
 
 # (config index, head, gradient allowance for deterministic ReLU sign flips; see test_gn_decoder_block_forward_backward)
-GN_CASES = [(0, 'p3d', FLIP), (1, 'p3d', FLIP), (0, 'concat', FLIP), (1, 'concat', FLIP)]
+GN_CASES = [(0, 'p3d'), (1, 'p3d'), (0, 'concat'), (1, 'concat')]
 
 
-@pytest.mark.parametrize("ci,head,flip_allowance", GN_CASES)
-def test_gn_cbam_forward_backward(ci, head, flip_allowance):
+@pytest.mark.parametrize("ci,head", GN_CASES)
+def test_gn_cbam_forward_backward(ci, head):
     """net='P3D' (gn/p3d_gn.py:214) and net='P3D_CONCAT' (gn/p3d_gn.py:279, deconv_pool4 at half the filters)."""
     cfg, shape = GN_SMALL[ci]
     from oracle import p3d_gn
@@ -373,21 +366,20 @@ def test_gn_cbam_forward_backward(ci, head, flip_allowance):
     # order (tests/test_gpu_determinism.py), so ONE run decides, and it must meet the fp32-noise bound on every tensor.
     loss, pred = s.backward(x, y, 0.0)
     assert abs(loss - l64) < 1e-5 * abs(l64)
-    errs = {n: rel_l2(s.get_grad(n), w, floor) for n, w in g64.items()}
-    bad = {n: e for n, e in errs.items() if e > 5 * rel_l2(g32[n], g64[n], floor) + 2e-3 + flip_allowance}
-    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
+    grad_gate("gn_cbam/%s_%d" % (head, ci), {n: rel_l2(s.get_grad(n), w, floor) for n, w in g64.items()},
+              {n: rel_l2(g32[n], w, floor) for n, w in g64.items()})
     s.close()
 
 
 # (config, clip shape, gradient allowance for ReLU sign flips -- see the comment in the test)
 GN_DECODER = [
-    (p3d.NetConfig(base=16, blocks=(1, 2, 2)), (2, 16, 32, 32), 6e-2),
-    (p3d.NetConfig(base=32, blocks=(1, 1, 2)), (1, 16, 48, 32), FLIP),
+    (p3d.NetConfig(base=16, blocks=(1, 2, 2)), (2, 16, 32, 32)),
+    (p3d.NetConfig(base=32, blocks=(1, 1, 2)), (1, 16, 48, 32)),
 ]
 
 
-@pytest.mark.parametrize("cfg,shape,flip_allowance", GN_DECODER)
-def test_gn_decoder_block_forward_backward(cfg, shape, flip_allowance):
+@pytest.mark.parametrize("cfg,shape", GN_DECODER)
+def test_gn_decoder_block_forward_backward(cfg, shape):
     """gn/p3d_gn.py:489 inference_p3d_decoder_block (net='P3D_DECODER'): variables under 'P3D/', transposed convs
     with kernel < stride ([1,3,3] by 4), base/4-channel full-resolution layers, stride-1 conv to one channel,
     dropout on its input."""
@@ -426,12 +418,12 @@ def test_gn_decoder_block_forward_backward(cfg, shape, flip_allowance):
     # flips none, so the oracle's own error is no yardstick there.  One flip in a layer of N elements moves that
     # layer's gradient by ~1/sqrt(N) = 0.3 % (twice that under dropout 0.5) and everything upstream inherits the
     # sum; the outcome is deterministic (tools/gn_decoder_probe.py).  The second config had no flip when measured
-    # (all gradients within 1e-5 of the oracle) and carries only the uniform FLIP allowance.
+    # (all gradients within 1e-5 of the oracle) and has to meet the fp32-noise bound itself (its measured gate is 0).
     loss, pred = s.backward(x, y, dropout=0.5, seed=11)
     assert abs(loss - l64) < 1e-5 * abs(l64)
     assert np.abs(pred - pr64).max() <= 1e-4 * max(np.abs(pr64).max(), 1.0)
-    for n, w in g64.items():
-        assert rel_l2(s.get_grad(n), w, floor) <= 5 * rel_l2(g32[n], w, floor) + 2e-3 + flip_allowance, n
+    grad_gate("gn_decoder/base%d_%s" % (cfg.base, "x".join(map(str, shape))), {n: rel_l2(s.get_grad(n), w, floor) for n, w in g64.items()},
+              {n: rel_l2(g32[n], w, floor) for n, w in g64.items()})
     s.close()
 
 
@@ -455,10 +447,7 @@ def test_dropout_forward_backward_parity():
     _, _, g32, _ = p3d.loss_and_grads(dict(p32), x, y, 0.5, True, 'unet', cfg, np.float32, keep_mask=keep.astype(np.float32))
     assert abs(loss - l64) < 1e-5 * abs(l64)
     assert np.abs(pred - pr64).max() < 1e-4
-    scale = np.median([np.linalg.norm(g) for g in g64.values()])
-    for n, want in g64.items():
-        floor = 1e-2 * scale
-        assert rel_l2(s.get_grad(n), want, floor) <= 5 * rel_l2(g32[n], want, floor) + 2e-3 + FLIP, n
+    grad_gate("dropout_parity", *grads_vs_oracles(s, g64, g32))
     s.close()
 
 

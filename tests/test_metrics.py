@@ -73,6 +73,55 @@ def test_oracle_resize_rules():
     assert out.min() >= (0 - 102) / 255.0 - 1e-6 and out.max() <= (255 - 90) / 255.0 + 1e-6
 
 
+def _resize_u8_scalar(im, H, W):
+    """cv::resize 8-bit INTER_LINEAR, one pixel at a time with Python integers -- written separately from the vectorised
+    oracle (oracle/dataflow.py::resize_linear_u8) so that the two restatements check each other."""
+    import math
+    H0, W0 = im.shape
+    out = np.zeros((H, W), np.uint8)
+    def table(dst, src, clamp_weight):
+        t = []
+        for d in range(dst):
+            f = np.float32((d + 0.5) * (src / dst) - 0.5)
+            s = math.floor(f)
+            f = np.float32(f - np.float32(s))
+            if clamp_weight and s < 0: s, f = 0, np.float32(0)
+            if clamp_weight and s >= src - 1: s, f = src - 1, np.float32(0)
+            w0 = int(np.rint(np.float32(np.float32(1) - f) * np.float32(2048)))
+            w1 = int(np.rint(f * np.float32(2048)))
+            t.append((min(max(s, 0), src - 1), min(max(s + 1, 0), src - 1), w0, w1))
+        return t
+    tx, ty = table(W, W0, True), table(H, H0, False)
+    for y, (y0, y1, b0, b1) in enumerate(ty):
+        for x, (x0, x1, a0, a1) in enumerate(tx):
+            r0 = int(im[y0, x0]) * a0 + int(im[y0, x1]) * a1
+            r1 = int(im[y1, x0]) * a0 + int(im[y1, x1]) * a1
+            out[y, x] = min(max((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, 0), 255)
+    return out
+
+
+def test_oracle_density_resize_is_opencvs_fixed_point_path():
+    """dataflow.py:210-214 resizes the uint8 density map before dividing by 255: the targets are k / 255.
+    Hand-computed vectors (11-bit weights, (>> 4, >> 16, + 2, >> 2) vertical pass):
+      [0, 255] -> width 4: weights (2048,0) (1536,512) (512,1536) (2048,0); rows 0, 130560, 391680, 522240 -> 0, 64, 191, 255
+      [10, 20, 30, 40] -> width 2 (2x down, weight 1024 each): (10+20)*1024 = 30720 -> 15, (30+40)*1024 -> 35
+      column [0, 100] -> height 3: f = -1/6 (rows clip, weights 1707 / 341 on the same row 0) -> 0;
+                                     f = 0.5 -> (1024*(0>>4)>>16) + (1024*(204800>>4)>>16) = 200 -> (200+2)>>2 = 50;
+                                     f = 1 + 1/6 -> floor 1, f' = 1/6: rows (1, clip 2 -> 1), weights 1707 + 341 -> 100"""
+    got = odf.resize_linear_u8(np.array([[0, 255]], np.uint8), 1, 4)
+    assert got.tolist() == [[0, 64, 191, 255]]
+    assert odf.resize_linear_u8(np.array([[10, 20, 30, 40]], np.uint8), 1, 2).tolist() == [[15, 35]]
+    assert odf.resize_linear_u8(np.array([[0], [100]], np.uint8), 3, 1).tolist() == [[0], [50], [100]]
+    rng = np.random.default_rng(3)
+    for (H0, W0, H, W) in ((9, 13, 5, 7), (5, 7, 9, 13), (30, 50, 16, 16), (16, 16, 16, 16), (7, 31, 12, 4)):
+        im = rng.integers(0, 256, (H0, W0), dtype=np.uint8)
+        assert np.array_equal(odf.resize_linear_u8(im, H, W), _resize_u8_scalar(im, H, W)), (H0, W0, H, W)
+    flat = odf.resize_linear_u8(np.full((33, 47), 200, np.uint8), 112, 112)
+    assert flat.min() == 200 and flat.max() == 200
+    d = odf.mapf_density(rng.integers(0, 256, (40, 60), dtype=np.uint8), 16, 16)
+    assert d.dtype == np.float32 and np.array_equal(d, (np.round(d.astype(np.float64) * 255) / 255.0).astype(np.float32))     # k / 255 exactly
+
+
 # ---- HIP kernels against the oracle --------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_cc_sim_nss_match_oracle():
@@ -163,6 +212,9 @@ def test_mapf_matches_oracle():
         dens = rng.integers(0, 256, (2, H0, W0), dtype=np.uint8)
         gd = gdf.mapf_density(dens, 112)
         wd = np.stack([odf.mapf_density(d, 112, 112) for d in dens])
-        assert np.abs(gd - wd).max() <= 1e-6
+        assert np.array_equal(gd, wd), (H0, W0)                 # byte arithmetic (uint8 fixed-point resize): bit-exact
+    for (H0, W0, H, W) in ((5, 7, 9, 13), (9, 13, 5, 7), (1, 2, 1, 4), (2, 1, 3, 1)):          # upscaling: clamped borders, clipped rows
+        dens = rng.integers(0, 256, (2, H0, W0), dtype=np.uint8)
+        assert np.array_equal(gdf.mapf_density(dens, (H, W)), np.stack([odf.mapf_density(d, H, W) for d in dens])), (H0, W0, H, W)
     with pytest.raises(ValueError):
         gdf.mapf_frames(np.zeros((2, 8, 8), np.uint8))

@@ -55,7 +55,7 @@ __global__ void fill_kernel(float* p, long long n, unsigned seed, float scale) {
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 5;
-    const bool quick = argc > 2;          // any second argument: 64x64 tiles only, no xmap arm
+    const bool quick = argc > 2;          // any second argument: 64x64 tiles only
     const int NW = 24;                 // distinct weight sets cycled through (cold weights)
     CK(hipSetDevice(0));
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -93,17 +93,9 @@ int main(int argc, char** argv) {
                 if (sp > kst / 2) continue;
                 const long long tl = ((M + tiles_cfg[ti][0] - 1) / tiles_cfg[ti][0]) * ((s.Nc + tiles_cfg[ti][1] - 1) / tiles_cfg[ti][1]);
                 if (tl * sp > 2048) continue;
-                for (int xm = 0; xm < 2; ++xm) {
-                    if (sp == 1 && xm) continue;
-                    if (quick && xm) continue;
-                    p3d_igemm2_override(ti, sp, xm);
+                {
+                    p3d_igemm2_override(ti, sp);
                     IgemmArgs a = make_args(s, x, y, w, zeros);
-#if defined(P3D_TUNE_STAMPS)
-                    static unsigned long long* stamps = nullptr;
-                    if (!stamps) CK(hipMalloc((void**)&stamps, 64));
-                    CK(hipMemset(stamps, 0, 64));
-                    a.stamps = stamps;
-#endif
                     const P3dIgemmPlan pl = p3d_igemm2_plan(a, 1);
                     float best = 1e30f;
                     for (int r = 0; r < reps + 1; ++r) {
@@ -126,24 +118,15 @@ int main(int argc, char** argv) {
                     CK(hipMemcpy(hy2.data(), y, M * s.Nc * 4, hipMemcpyDeviceToHost));
                     const bool same = memcmp(hy.data(), hy2.data(), M * s.Nc * 4) == 0;
                     const double us = best * 1e3 / NW;
-                    printf("   tile %3dx%-3d splits %2d xmap %d blocks %4lld : %7.2f us  %6.1f TF/s  relerr %.1e %s\n", pl.bm, pl.bn, pl.splits, pl.xmap,
+                    printf("   tile %3dx%-3d splits %2d blocks %4lld : %7.2f us  %6.1f TF/s  relerr %.1e %s\n", pl.bm, pl.bn, pl.splits,
                            tl * sp, us, 2.0 * M * s.K * s.Nc * s.kd * s.kh * s.kw / us / 1e6, err / (mag + 1e-30), same ? "" : "NONDETERMINISTIC");
-#if defined(P3D_TUNE_STAMPS)
-                    {   // block 0 / wave 0, summed over every launch of this plan: shader cycles
-                        unsigned long long hs[8];
-                        CK(hipMemcpy(hs, stamps, 64, hipMemcpyDeviceToHost));
-                        const double st_n = (double)std::max(1ull, hs[2]), k_n = (double)std::max(1ull, hs[5]);
-                        printf("        per step: wait for the stage %.0f cyc, fragments + MFMAs + DMA issue %.0f cyc (%.0f steps/kernel); "
-                               "per kernel: prologue %.0f cyc (row table %.0f, loader init %.0f), epilogue %.0f cyc\n", hs[0] / st_n, hs[1] / st_n, st_n / k_n, hs[3] / k_n, hs[6] / k_n, hs[7] / k_n, hs[4] / k_n);
-                    }
-#endif
                     fflush(stdout);
                 }
             }
         }
         CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(yref)); CK(hipFree(w));
     }
-    p3d_igemm2_override(-1, 0, -1);
+    p3d_igemm2_override(-1, 0);
 
     // ---- weight gradients of one stage-3 / stage-2 bottleneck: four launches vs one grouped launch -------------------
     for (int stage = 3; stage >= 2; --stage) {

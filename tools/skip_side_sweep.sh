@@ -1,3 +1,7 @@
+# The switches below exist only in a -DP3D_TUNING build of the library (the product build ignores them): rebuild on the GPU box first.
+P3D_EXTRA_HIPCC_FLAGS=-DP3D_TUNING python -c "
+import sys; sys.path.insert(0,'.')
+from sap3d_tensorflow_amd import build; build.build(force=True)" > /dev/null 2>&1 || { echo "tuning build failed"; exit 1; }
 mkdir -p gpurun_out/r2s
 S3=$(python3 -c "print(','.join('block%d/'%i for i in range(11,47)))")
 S2=$(python3 -c "print(','.join('block%d/'%i for i in range(3,11)))")

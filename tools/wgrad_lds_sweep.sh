@@ -1,3 +1,7 @@
+# The switches below exist only in a -DP3D_TUNING build of the library (the product build ignores them): rebuild on the GPU box first.
+P3D_EXTRA_HIPCC_FLAGS=-DP3D_TUNING python -c "
+import sys; sys.path.insert(0,'.')
+from sap3d_tensorflow_amd import build; build.build(force=True)" > /dev/null 2>&1 || { echo "tuning build failed"; exit 1; }
 # bench.py with the filter-gradient kernel's LDS request (= blocks per CU) and the plan's slots per CU swept
 #   gpurun -- 'CASES="82:3 82:6" bash tools/wgrad_lds_sweep.sh'
 mkdir -p gpurun_out/lds
