@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -174,6 +175,7 @@ void launch(const Ctx& c, const char* kernel, double flops, double bytes, F&& f)
     c.prof->recs.push_back(r);
 }
 
+std::atomic<int> g_live_handles{0};      // p3d_create .. p3d_destroy; p3d_shutdown refuses while any is alive
 const float* g_zero_page = nullptr;      // 1 KiB of zeros (device), set by p3d_create / op entry points
 
 void igemm_work(const IgemmArgs& a, double& flops, double& bytes) {
@@ -2513,6 +2515,7 @@ int p3d_create(const p3d_config* cfg, p3d_handle** out) {
         h->finalize_build();
         HIPCHECK(hipStreamSynchronize(h->stream));
         *out = h;
+        ++g_live_handles;
     } catch (const std::exception& e) {
         g_err = e.what();
         delete h;
@@ -2526,6 +2529,7 @@ void p3d_destroy(p3d_handle* h) {
     hipSetDevice(h->cfg.device);
     hipDeviceSynchronize();
     delete h;
+    --g_live_handles;
 }
 
 int p3d_num_params(p3d_handle* h) { return h ? (int)h->porder.size() : -1; }
@@ -3203,6 +3207,8 @@ uint32_t p3d_crc32c(const void* data, size_t n, uint32_t crc) {
 
 int p3d_shutdown(void) {
     API_BEGIN
+    if (g_live_handles.load() > 0)
+        throw P3dError("p3d_shutdown with " + std::to_string(g_live_handles.load()) + " live handle(s): destroy them first (their scratch and captured graphs name the pools this call frees)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return 0;
     hipDeviceSynchronize();

@@ -56,11 +56,88 @@ def crc32c(data, crc=0):
         native = _native_crc()
         if native is not None:
             return native(mv, crc)
+    if len(mv) >= 1 << 12:
+        return _crc32c_numpy(mv, crc)
     c = crc ^ 0xFFFFFFFF
     tab = _TABLE_LIST
     for b in mv:
         c = tab[(c ^ b) & 0xFF] ^ (c >> 8)
     return c ^ 0xFFFFFFFF
+
+
+_TABLES8 = None
+
+
+def _crc32c_numpy(mv, crc):
+    """Slicing-by-8 with numpy for when libp3dhip cannot be loaded: the buffer is cut into 256 lanes that are checksummed
+    side by side (vectorised over the lanes, eight bytes per step through eight tables) and stitched together with the
+    zero-extension operator of the CRC (crc(A || B) = shift(crc(A), len(B)) xor crc'(B)); the ragged tail goes byte by byte."""
+    global _TABLES8
+    if _TABLES8 is None:
+        t = np.zeros((8, 256), np.uint32)
+        t[0] = _TABLE
+        for k in range(1, 8):
+            t[k] = t[0][t[k - 1] & 0xFF] ^ (t[k - 1] >> 8)
+        _TABLES8 = t
+    t = _TABLES8
+    data = np.frombuffer(mv, np.uint8)
+    lanes = 256
+    per = (len(data) // lanes) // 8 * 8
+    c = crc ^ 0xFFFFFFFF
+    if per:
+        body = data[:lanes * per].reshape(lanes, per // 8, 8)
+        st = np.zeros(lanes, np.uint32)
+        st[0] = c                                           # only the first lane continues the running CRC
+        for j in range(per // 8):
+            w = body[:, j, :].astype(np.uint32)
+            lo = st ^ (w[:, 0] | (w[:, 1] << 8) | (w[:, 2] << 16) | (w[:, 3] << 24))
+            st = (t[7][lo & 0xFF] ^ t[6][(lo >> 8) & 0xFF] ^ t[5][(lo >> 16) & 0xFF] ^ t[4][lo >> 24] ^
+                  t[3][w[:, 4]] ^ t[2][w[:, 5]] ^ t[1][w[:, 6]] ^ t[0][w[:, 7]])
+        # stitch: advance lane i's register over the bytes of the lanes behind it = feed `per` zero bytes, lane by lane
+        zero_step = _zero_operator(per)
+        c = int(st[0])
+        for i in range(1, lanes):
+            c = _apply_operator(zero_step, c) ^ int(st[i])
+    tab = _TABLE_LIST
+    for b in data[lanes * per:].tolist():
+        c = tab[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _apply_operator(op, c):
+    out = 0
+    i = 0
+    while c:
+        if c & 1:
+            out ^= op[i]
+        c >>= 1
+        i += 1
+    return out
+
+
+_ZERO_OPS = {}
+
+
+def _zero_operator(nbytes):
+    """32x32 GF(2) matrix (as 32 column words) that advances a CRC register over `nbytes` zero bytes."""
+    if nbytes in _ZERO_OPS:
+        return _ZERO_OPS[nbytes]
+    one = []                                                # one zero BYTE: register bit i -> table walk of that bit
+    for i in range(32):
+        c = 1 << i
+        c = _TABLE_LIST[c & 0xFF] ^ (c >> 8)
+        one.append(c)
+    def mul(a, b):                                          # (a o b)(x) = a(b(x))
+        return [_apply_operator(a, col) for col in b]
+    result = None
+    power, n = one, nbytes
+    while n:
+        if n & 1:
+            result = power if result is None else mul(power, result)
+        power = mul(power, power)
+        n >>= 1
+    _ZERO_OPS[nbytes] = result
+    return result
 
 
 _native = False
@@ -412,10 +489,11 @@ def update_checkpoint_state(directory, prefix, keep=10):
         f.write('model_checkpoint_path: "%s"\n' % rel)
         for p in paths:
             f.write('all_model_checkpoint_paths: "%s"\n' % p)
-    for p in dropped:                                   # Saver deletes what falls out of the window
-        for fn in (p + ".index", data_file(p, 0, 1)):
+    import glob
+    for p in dropped:                                   # Saver deletes what falls out of the window: every file of the prefix
+        for fn in glob.glob(glob.escape(os.path.join(directory, p)) + ".*"):      # .index, every .data-?????-of-?????, a TF-written .meta
             try:
-                os.remove(os.path.join(directory, fn))
+                os.remove(fn)
             except OSError:
                 pass
 

@@ -122,3 +122,35 @@ def test_session_restores_a_bundle(tmp_path):
     with pytest.raises(KeyError):
         c.restore(prefix)            # another head: variables missing from the bundle
     a.close(); b.close(); c.close()
+
+
+def test_numpy_crc_fallback_matches_the_byte_loop():
+    """The fallback used when libp3dhip cannot be loaded (256 lanes, slicing-by-8, stitched with the CRC's zero-extension
+    operator) against the byte-at-a-time definition, with and without a running value, ragged tails included."""
+    rng = np.random.default_rng(0)
+
+    def slow(b, crc=0):
+        c = crc ^ 0xFFFFFFFF
+        for x in b:
+            c = tfc._TABLE_LIST[(c ^ x) & 0xFF] ^ (c >> 8)
+        return c ^ 0xFFFFFFFF
+
+    for n in (4096, 4097, 5000, 70001):
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert tfc._crc32c_numpy(memoryview(b), 0) == slow(b)
+        assert tfc._crc32c_numpy(memoryview(b), 0xDEADBEEF) == slow(b, 0xDEADBEEF)
+    assert tfc._crc32c_numpy(memoryview(b"123456789" * 1000), 0) == slow(b"123456789" * 1000)
+
+
+def test_dropped_checkpoints_lose_every_file_of_their_prefix(tmp_path):
+    """tf.train.Saver(max_to_keep) removes whatever belongs to a dropped prefix: .index, every data shard, a TF-written .meta."""
+    d = str(tmp_path)
+    for step in (1, 2, 3):
+        prefix = os.path.join(d, "p3d_%d.ckpt" % step)
+        tfc.write_checkpoint(prefix, {"w": np.arange(4, dtype=np.float32)})
+        open(prefix + ".meta", "w").write("graph")                 # what a TensorFlow-written checkpoint also leaves
+        open(prefix + ".data-00001-of-00002", "w").write("shard")
+        tfc.update_checkpoint_state(d, prefix, keep=2)
+    left = sorted(os.listdir(d))
+    assert not [f for f in left if f.startswith("p3d_1.ckpt")], left
+    assert [f for f in left if f.startswith("p3d_2.ckpt")] and [f for f in left if f.startswith("p3d_3.ckpt")]
