@@ -102,9 +102,9 @@ __device__ __forceinline__ void a_init(const IgemmArgs& p, ALoad<BM / 32, TWO>& 
         if (TWO) st.aptr2[TWO ? i : 0] = nullptr;
         st.achunk[i] = 4 * (a_slot ^ ((r >> 1) & 7));
         if (m < M) {
-            const unsigned gw = m % (unsigned)p.Gw; unsigned t = m / (unsigned)p.Gw;
-            const unsigned gh = t % (unsigned)p.Gh; t /= (unsigned)p.Gh;
-            const unsigned gd = t % (unsigned)p.Gd; const unsigned n = t / (unsigned)p.Gd;
+            const unsigned t1 = p3d_div(m, p.fGw), gw = m - t1 * (unsigned)p.Gw;
+            const unsigned t2 = p3d_div(t1, p.fGh), gh = t1 - t2 * (unsigned)p.Gh;
+            const unsigned n = p3d_div(t2, p.fGd), gd = t2 - n * (unsigned)p.Gd;
             st.base[i] = (int)n * p.Di * p.Hi * p.Wi;
             st.dhw[i] = (int)(((gd * p.isd) << 20) | ((gh * p.ish) << 10) | (gw * p.isw));
         }
@@ -558,9 +558,9 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
         const unsigned m = m0u + r;
         int ro = -1;
         if (m < Mu) {
-            const unsigned gw = m % (unsigned)p.Gw; unsigned t = m / (unsigned)p.Gw;
-            const unsigned gh = t % (unsigned)p.Gh; t /= (unsigned)p.Gh;
-            const unsigned gd = t % (unsigned)p.Gd; const unsigned n = t / (unsigned)p.Gd;
+            const unsigned t1 = p3d_div(m, p.fGw), gw = m - t1 * (unsigned)p.Gw;
+            const unsigned t2 = p3d_div(t1, p.fGh), gh = t1 - t2 * (unsigned)p.Gh;
+            const unsigned n = p3d_div(t2, p.fGd), gd = t2 - n * (unsigned)p.Gd;
             const int od = gd * p.osd + p.ood, oh = gh * p.osh + p.ooh, ow = gw * p.osw + p.oow;
             ro = (((int)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
         }
@@ -975,6 +975,7 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int) {
 
 hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) {
     IgemmArgs a = a0;
+    a.fGd = p3d_fastdiv((unsigned)a.Gd); a.fGh = p3d_fastdiv((unsigned)a.Gh); a.fGw = p3d_fastdiv((unsigned)a.Gw);
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     if (M <= 0 || a.Nc <= 0) return hipSuccess;
     if (M >= (1ll << 31) || (long long)a.N * a.Di * a.Hi * a.Wi >= (1ll << 31)) return hipErrorInvalidValue;

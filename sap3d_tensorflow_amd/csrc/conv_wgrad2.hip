@@ -56,6 +56,7 @@ struct WProb {
     const float* x; const float* dy; float* dw; float* dbias;
     int N, Di, Hi, Wi, ldx, K;
     int Gd, Gh, Gw, isd, ish, isw;
+    P3dFastDiv fGd, fGh, fGw;
     int ldy, Nc;
     int ksplit;          // cuts of the position range
     int blk0;            // first block of this problem in the launch's 1-D grid
@@ -76,7 +77,7 @@ struct WGroup {
     int kstride;         // slab index of (slot, cut) = slot * kstride + cut
     WProb p[P3D_WGRAD_GROUP];
 };
-static_assert(sizeof(WGroup) <= 3900, "kernel arguments must stay under the 4 KB kernarg segment");
+static_assert(sizeof(WGroup) <= 4000, "kernel arguments must stay under the 4 KB kernarg segment");
 
 // Per-lane loader state in registers: the lattice coordinates of the rows this lane fetches, advanced
 // by 32 positions per step with small-integer reciprocal carries (no per-step division).
@@ -102,9 +103,9 @@ __device__ __forceinline__ void wloader_init(const WProb& p, WState<BM / 32, BN 
     for (int i = 0; i < LA; ++i) {
         const unsigned m = ms + (i * 4 + wave) * A_RPP + lane / A_LPR;
         st.m[i] = m;
-        st.gw[i] = (int)(m % (unsigned)p.Gw); unsigned t = m / (unsigned)p.Gw;
-        st.gh[i] = (int)(t % (unsigned)p.Gh); t /= (unsigned)p.Gh;
-        st.gd[i] = (int)(t % (unsigned)p.Gd); st.n[i] = (int)(t / (unsigned)p.Gd);
+        const unsigned t1 = p3d_div(m, p.fGw), t2 = p3d_div(t1, p.fGh), nn = p3d_div(t2, p.fGd);
+        st.gw[i] = (int)(m - t1 * (unsigned)p.Gw); st.gh[i] = (int)(t1 - t2 * (unsigned)p.Gh);
+        st.gd[i] = (int)(t2 - nn * (unsigned)p.Gd); st.n[i] = (int)nn;
         st.kc[i] = p.pair ? ((lane % A_LPR) % (A_LPR / 2)) * 4 : k0 + (lane % A_LPR) * 4;
     }
 #pragma unroll
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
         p.x = src.x; p.dy = src.dy; p.dw = src.dw; p.dbias = src.dbias;
         p.N = src.N; p.Di = src.Di; p.Hi = src.Hi; p.Wi = src.Wi; p.ldx = src.ldx; p.K = src.K;
         p.Gd = src.Gd; p.Gh = src.Gh; p.Gw = src.Gw; p.isd = src.isd; p.ish = src.ish; p.isw = src.isw;
+        p.fGd = src.fGd; p.fGh = src.fGh; p.fGw = src.fGw;
         p.ldy = src.ldy; p.Nc = src.Nc; p.ksplit = src.ksplit; p.blk0 = src.blk0; p.tile0 = src.tile0; p.ntaps = src.ntaps;
         p.pair = src.pair;
         p.xt = FUSED ? src.xt : 0; p.dyt = FUSED ? src.dyt : 0; p.ldx2 = src.ldx2; p.ldy2 = src.ldy2;
@@ -694,6 +696,7 @@ void fill_prob(WProb& p, const WgradArgs& a) {
     p.x = a.x; p.dy = a.dy; p.dw = a.dw; p.dbias = a.dbias;
     p.N = a.N; p.Di = a.Di; p.Hi = a.Hi; p.Wi = a.Wi; p.ldx = a.ldx; p.K = a.K;
     p.Gd = a.Gd; p.Gh = a.Gh; p.Gw = a.Gw; p.isd = a.isd; p.ish = a.ish; p.isw = a.isw;
+    p.fGd = p3d_fastdiv((unsigned)a.Gd); p.fGh = p3d_fastdiv((unsigned)a.Gh); p.fGw = p3d_fastdiv((unsigned)a.Gw);
     p.ldy = a.ldy; p.Nc = a.Nc; p.ntaps = a.ntaps; p.pair = a.pair;
     p.xt = a.xt; p.dyt = a.dyt ? 1 : 0; p.ldx2 = a.ldx2; p.ldy2 = a.ldy2;
     p.x2 = a.x2; p.xs1 = a.xs1; p.xt1 = a.xt1; p.xs2 = a.xs2; p.xt2 = a.xt2; p.dy2 = a.dy2; p.dcoef = a.dcoef;

@@ -32,6 +32,24 @@ inline const char* p3d_tune_env(const char* name) {
 #endif
 }
 
+// Division by a launch-invariant extent without the ~40-instruction udiv expansion (the kernels' prologues decode linear
+// positions into lattice coordinates): q = floor(n / d) for 0 <= n < 2^31 as mulhi(n, mul) >> shift with
+// mul = ceil(2^(31+l) / d), l = ceil(log2 d) (Granlund & Montgomery, "Division by invariant integers", Thm 4.2); d = 1: mul = 0.
+// (Measured: no change of any launch time -- the divisions sat in the shadow of the first loads -- kept for the shorter code.)
+struct P3dFastDiv { unsigned mul; int shift; };
+inline P3dFastDiv p3d_fastdiv(unsigned d) {
+    P3dFastDiv f{0u, 0};
+    if (d <= 1) return f;
+    int l = 0;
+    while ((1u << l) < d) ++l;
+    f.mul = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+    f.shift = l - 1;
+    return f;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned p3d_div(unsigned n, P3dFastDiv f) { return f.mul ? (__umulhi(n, f.mul) >> f.shift) : n; }
+#endif
+
 struct P3dTap {
     int16_t dd, dh, dw;   // gathered coordinate = g*is + d{d,h,w}
     int16_t widx;         // which [K][N] slab of the weight tensor
@@ -79,6 +97,7 @@ struct IgemmArgs {
     int ldx;              // floats per gathered-side position
     int K;                // reduction channels (Cin of this GEMM)
     int Gd, Gh, Gw;       // iteration grid per sample; M = N*Gd*Gh*Gw
+    P3dFastDiv fGd, fGh, fGw;   // (filled by the launcher)
     int isd, ish, isw;    // gathered coord = g*is + tap offset
     float* y;             // output (already offset to its channel slice)
     int Do, Ho, Wo;       // output extents

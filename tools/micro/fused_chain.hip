@@ -114,6 +114,31 @@ int main(int argc, char** argv) {
             printf("   %dx%d splits %d  %-70s %7.2f us\n", pl.bm, pl.bn, pl.splits, v.name, best * 1e3 / NW);
             fflush(stdout);
         }
+        {   // co-residency: the same plain chain on TWO streams at once (twice the blocks on the chip).  If two blocks that share
+            // a CU (two waves per SIMD) interleave for free, both chains finish in the time of one.
+            static hipStream_t st2 = nullptr;
+            if (!st2) CK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+            IgemmArgs a = vs[0].a, b = vs[0].a;
+            b.y = yb;
+            const P3dIgemmPlan pl = p3d_igemm2_plan(a, 1);
+            hipEvent_t f0, f1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
+            float best = 1e30f;
+            for (int r = 0; r < reps + 1; ++r) {
+                CK(hipEventRecord(e0, st));
+                CK(hipStreamWaitEvent(st2, e0, 0));
+                for (int i = 0; i < NW; ++i) {
+                    a.w = w + (long long)i * wsz; b.w = a.w;
+                    CK(p3d_launch_igemm2(a, pl, st)); CK(p3d_launch_igemm2(b, pl, st2));
+                }
+                CK(hipEventRecord(f1, st2));
+                CK(hipStreamWaitEvent(st, f1, 0));
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (r > 0) best = std::min(best, ms);
+            }
+            printf("   %dx%d splits %d  %-70s %7.2f us per PAIR of launches\n", pl.bm, pl.bn, pl.splits, "plain, two chains on two streams", best * 1e3 / NW);
+        }
         for (float* p : {x, x2, y, yb, g1, g2, w, ones, small, scr, part, statpart, coef}) CK(hipFree(p));
     }
     return 0;
