@@ -63,6 +63,7 @@ constexpr int EPT = 16;
 
 template <int TPR>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* s, long long rows, int cols, int ld) {
+    P3D_CHAIN_PRIO();
     __shared__ float red[4];
     const int rpb = 256 / TPR;
     const int t = threadIdx.x % TPR;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* s, long long ro
 // ds = beta * (dbeta - <beta, dbeta>), written over dbeta; padded columns -> 0
 template <int TPR>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* beta, float* d, long long rows, int cols, int ld) {
+    P3D_CHAIN_PRIO();
     __shared__ float red[4];
     const int rpb = 256 / TPR;
     const int t = threadIdx.x % TPR;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* beta, flo
 
 // z = r * gamma + x, optional inverted dropout on z (keyed like every other dropout of the path)
 __global__ __launch_bounds__(256) void mix_fwd_kernel(AttnMixArgs a) {
+    P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = a.M * c4n;
     const float gm = a.gamma[0];
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(256) void mix_fwd_kernel(AttnMixArgs a) {
 
 // dr = dz' * gamma; dx (+)= dz'; dgamma += sum dz' * r        (dz' = dz with the dropout mask)
 __global__ __launch_bounds__(256) void mix_bwd_kernel(AttnMixArgs a) {
+    P3D_CHAIN_PRIO();
     __shared__ float red[4];
     const int c4n = a.C >> 2;
     const long long total = a.M * c4n;
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(AttnMixArgs a) {
 
 // dst[b][0..Npad) x C  <-  src[b][0..N) x C, rows N..Npad zero  (add = 1: src[b][r] += dst... the reverse, for gradients)
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* src, float* dst, int B, int N, int Npad, int C) {
+    P3D_CHAIN_PRIO();
     const int c4n = C >> 2;
     const long long total = (long long)B * Npad * c4n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -215,6 +220,7 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* src, float* 
     }
 }
 __global__ __launch_bounds__(256) void unpad_rows_kernel(const float* src, float* dst, int B, int N, int Npad, int C) {
+    P3D_CHAIN_PRIO();
     const int c4n = C >> 2;
     const long long total = (long long)B * N * c4n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {

@@ -78,6 +78,7 @@ __device__ __forceinline__ void bn_coeffs(const BnParams& bn, int c, bool use_ba
 
 template <int MODE, int CBW>
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(BnSmallArgs a) {
+    P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 2 || MODE == 3);
     constexpr int G = CBW / 4, RS = 256 / G, MJ = 1024 / RS;
     __shared__ float4 xch[16 * G];
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(BnSmallArgs a) {
 
 template <int MODE, int CBW>
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(BnSmallArgs a) {
+    P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 2 || MODE == 3);
     constexpr int G = CBW / 4, RS = 256 / G, MJ = 1024 / RS;
     __shared__ float4 xch[16 * G];

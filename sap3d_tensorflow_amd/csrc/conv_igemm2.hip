@@ -34,6 +34,7 @@
 #include "p3d_kernels.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -89,8 +90,17 @@ struct BLoad {
     int t, kc, issued;
 };
 
+// The per-class part of a launch as the kernel body sees it: from the kernel arguments themselves (one class) or from the
+// class table of a grouped launch
+struct Geo {
+    int Gd, Gh, Gw;
+    P3dFastDiv fGd, fGh, fGw;
+    int ood, ooh, oow, stat_base, ntaps;
+    const P3dTap* taps;
+};
+
 template <int BM, bool TWO>
-__device__ __forceinline__ void a_init(const IgemmArgs& p, ALoad<BM / 32, TWO>& st, unsigned m0, unsigned M, int wave, int lane,
+__device__ __forceinline__ void a_init(const IgemmArgs& p, const Geo& geo, ALoad<BM / 32, TWO>& st, unsigned m0, unsigned M, int wave, int lane,
                                        int s_begin, int kchunks) {
     constexpr int LA = BM / 32;
     const int a_slot = lane & 7, a_sub = lane >> 3;
@@ -102,9 +112,9 @@ __device__ __forceinline__ void a_init(const IgemmArgs& p, ALoad<BM / 32, TWO>& 
         if (TWO) st.aptr2[TWO ? i : 0] = nullptr;
         st.achunk[i] = 4 * (a_slot ^ ((r >> 1) & 7));
         if (m < M) {
-            const unsigned t1 = p3d_div(m, p.fGw), gw = m - t1 * (unsigned)p.Gw;
-            const unsigned t2 = p3d_div(t1, p.fGh), gh = t1 - t2 * (unsigned)p.Gh;
-            const unsigned n = p3d_div(t2, p.fGd), gd = t2 - n * (unsigned)p.Gd;
+            const unsigned t1 = p3d_div(m, geo.fGw), gw = m - t1 * (unsigned)geo.Gw;
+            const unsigned t2 = p3d_div(t1, geo.fGh), gh = t1 - t2 * (unsigned)geo.Gh;
+            const unsigned n = p3d_div(t2, geo.fGd), gd = t2 - n * (unsigned)geo.Gd;
             st.base[i] = (int)n * p.Di * p.Hi * p.Wi;
             st.dhw[i] = (int)(((gd * p.isd) << 20) | ((gh * p.ish) << 10) | (gw * p.isw));
         }
@@ -136,8 +146,8 @@ __device__ __forceinline__ void b_init(const IgemmArgs& p, BLoad<BN / 32>& st, i
 }
 
 template <int LA, bool TWO>
-__device__ __forceinline__ void a_set_tap(const IgemmArgs& p, ALoad<LA, TWO>& st) {
-    const P3dTap tap = p.taps[st.t];
+__device__ __forceinline__ void a_set_tap(const IgemmArgs& p, const P3dTap* taps, ALoad<LA, TWO>& st) {
+    const P3dTap tap = taps[st.t];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int id = (st.dhw[i] >> 20) + tap.dd, ih = ((st.dhw[i] >> 10) & 1023) + tap.dh, iw = (st.dhw[i] & 1023) + tap.dw;
@@ -154,11 +164,11 @@ __device__ __forceinline__ void a_set_tap(const IgemmArgs& p, ALoad<LA, TWO>& st
 // __restrict__ so that, inlined next to the fragment reads, hipcc knows the reads cannot alias the DMA
 // targets and does not put s_waitcnt vmcnt(0) in front of them.
 template <int BM>
-__device__ __forceinline__ void issue_a_dma(const IgemmArgs& p, float* __restrict__ a_dst, ALoad<BM / 32, false>& st, int nsteps,
+__device__ __forceinline__ void issue_a_dma(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ a_dst, ALoad<BM / 32, false>& st, int nsteps,
                                             int kchunks, bool first, int wave, int lane) {
     constexpr int LA = BM / 32;
     const bool live = st.issued < nsteps;
-    if (live && (first || st.kc == 0)) a_set_tap(p, st);      // wave-uniform, once per tap
+    if (live && (first || st.kc == 0)) a_set_tap(p, taps, st);      // wave-uniform, once per tap
     const int k0 = st.kc * BK;
     const float* zp = p.zeros + 4 * (lane & 7);
 #pragma unroll
@@ -170,13 +180,13 @@ __device__ __forceinline__ void issue_a_dma(const IgemmArgs& p, float* __restric
     if (++st.kc == kchunks) { st.kc = 0; ++st.t; }
 }
 template <int BN, bool WT>
-__device__ __forceinline__ void issue_b_dma(const IgemmArgs& p, float* __restrict__ b_dst, BLoad<BN / 32>& st, int nsteps, int kchunks,
+__device__ __forceinline__ void issue_b_dma(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ b_dst, BLoad<BN / 32>& st, int nsteps, int kchunks,
                                             int wave, int lane) {
     constexpr int LB = BN / 32;
     const bool live = st.issued < nsteps;
     const int k0 = st.kc * BK;
     const float* zp = p.zeros + 4 * (lane & 7);
-    const float* wt = p.w + (long long)p.taps[live ? st.t : 0].widx * p.K * p.Nc;
+    const float* wt = p.w + (long long)taps[live ? st.t : 0].widx * p.K * p.Nc;
     if (!WT) {
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
@@ -207,12 +217,12 @@ struct AMeta {
     int k0;                  // channel base of the step (coefficient table offset)
 };
 template <int BM, int AT>
-__device__ __forceinline__ void issue_a_raw(const IgemmArgs& p, float* __restrict__ raw_dst, float* __restrict__ raw2_dst, AMeta& r,
+__device__ __forceinline__ void issue_a_raw(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ raw_dst, float* __restrict__ raw2_dst, AMeta& r,
                                             ALoad<BM / 32, ATr<AT>::two>& st, int nsteps, int kchunks, bool first, int wave, int lane) {
     constexpr int LA = BM / 32;
     constexpr bool TWO = ATr<AT>::two;
     const bool live = st.issued < nsteps;
-    if (live && (first || st.kc == 0)) a_set_tap(p, st);
+    if (live && (first || st.kc == 0)) a_set_tap(p, taps, st);
     const int k0 = st.kc * BK;
     const float* zp = p.zeros + 4 * (lane & 7);
     r.ok = 0; r.k0 = k0;
@@ -370,7 +380,7 @@ struct Lds {      // float offsets inside the ring region
 // Branch-free: wait for this step's loads, barrier, read the stage's fragments, first half of the MFMAs, issue step+2,
 // second half.
 template <int BM, int BN, bool WT, bool F16>
-__device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict__ a_dst, float* __restrict__ b_dst,
+__device__ __forceinline__ void pipe_step(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ a_dst, float* __restrict__ b_dst,
                                           const float* __restrict__ a_src, const float* __restrict__ b_src,
                                           f32x16 (&acc)[BM / 64][BN / 64], ALoad<BM / 32, false>& sa, BLoad<BN / 32>& sb, int nsteps,
                                           int kchunks, int wave, int lane, int wm, int wn) {
@@ -382,15 +392,15 @@ __device__ __forceinline__ void pipe_step(const IgemmArgs& p, float* __restrict_
     load_frags<BM, BN, WT>(a_src, b_src, f, wm, wn, lane >> 5, lane & 31);
     __builtin_amdgcn_sched_barrier(0);      // keep every read above the MFMAs (hipcc otherwise sinks half of them back)
     mfma_frags<BM, BN, WT, F16, 0, BK / 16>(f, acc);
-    issue_a_dma<BM>(p, a_dst, sa, nsteps, kchunks, false, wave, lane);
-    issue_b_dma<BN, WT>(p, b_dst, sb, nsteps, kchunks, wave, lane);
+    issue_a_dma<BM>(p, taps, a_dst, sa, nsteps, kchunks, false, wave, lane);
+    issue_b_dma<BN, WT>(p, taps, b_dst, sb, nsteps, kchunks, wave, lane);
     mfma_frags<BM, BN, WT, F16, BK / 16, BK / 8>(f, acc);
 }
 // ... and of the fused-BatchNorm kernel: the A slot consumed now was written (transformed) during the previous step;
 // between the MFMA halves the lane transforms the NEXT step's A chunks out of their raw slot, then re-targets that raw slot
 // with the DMA of STAGES steps ahead and issues the B DMA of STAGES - 1 steps ahead.
 template <int BM, int BN, bool WT, bool F16, int AT>
-__device__ __forceinline__ void pipe_step_fused(const IgemmArgs& p, float* __restrict__ a_next, float* __restrict__ b_dst,
+__device__ __forceinline__ void pipe_step_fused(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ a_next, float* __restrict__ b_dst,
                                                 float* __restrict__ raw, float* __restrict__ raw2,
                                                 const float* __restrict__ a_src, const float* __restrict__ b_src,
                                                 const float* __restrict__ tab, int kp, f32x16 (&acc)[BM / 64][BN / 64],
@@ -407,31 +417,31 @@ __device__ __forceinline__ void pipe_step_fused(const IgemmArgs& p, float* __res
     __builtin_amdgcn_sched_barrier(0);
     mfma_frags<BM, BN, WT, F16, 0, BK / 16>(f, acc);
     transform_store<BM, AT>(r, xin, a_next, wave, lane);
-    issue_a_raw<BM, AT>(p, raw, raw2, r, sa, nsteps, kchunks, false, wave, lane);
-    issue_b_dma<BN, WT>(p, b_dst, sb, nsteps, kchunks, wave, lane);
+    issue_a_raw<BM, AT>(p, taps, raw, raw2, r, sa, nsteps, kchunks, false, wave, lane);
+    issue_b_dma<BN, WT>(p, taps, b_dst, sb, nsteps, kchunks, wave, lane);
     mfma_frags<BM, BN, WT, F16, BK / 16, BK / 8>(f, acc);
 }
 
 template <int BM, int BN, bool WT, bool F16, int K>
 struct StepLoop {
-    static __device__ __forceinline__ void run(const IgemmArgs& p, float* ring, f32x16 (&acc)[BM / 64][BN / 64],
+    static __device__ __forceinline__ void run(const IgemmArgs& p, const P3dTap* taps, float* ring, f32x16 (&acc)[BM / 64][BN / 64],
                                                ALoad<BM / 32, false>& sa, BLoad<BN / 32>& sb, int base, int nsteps, int kchunks,
                                                int wave, int lane, int wm, int wn) {
         using L = Lds<BM, BN, 0>;
         if constexpr (K < L::STAGES) {
             if (base + K < nsteps) {
                 constexpr int D = (K + L::STAGES - 1) % L::STAGES;      // stage refilled while stage K is consumed
-                pipe_step<BM, BN, WT, F16>(p, ring + D * L::A_STAGE, ring + L::B_OFF + D * L::B_STAGE, ring + K * L::A_STAGE,
+                pipe_step<BM, BN, WT, F16>(p, taps, ring + D * L::A_STAGE, ring + L::B_OFF + D * L::B_STAGE, ring + K * L::A_STAGE,
                                            ring + L::B_OFF + K * L::B_STAGE, acc, sa, sb, nsteps, kchunks, wave, lane, wm, wn);
             }
-            StepLoop<BM, BN, WT, F16, K + 1>::run(p, ring, acc, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
+            StepLoop<BM, BN, WT, F16, K + 1>::run(p, taps, ring, acc, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
         }
     }
 };
 // fused: the period of (B slot, A slot, raw slot) is STAGES * (STAGES - 1) steps, all indices compile-time
 template <int BM, int BN, bool WT, bool F16, int AT, int K>
 struct FusedLoop {
-    static __device__ __forceinline__ void run(const IgemmArgs& p, float* ring, const float* tab, int kp, f32x16 (&acc)[BM / 64][BN / 64],
+    static __device__ __forceinline__ void run(const IgemmArgs& p, const P3dTap* taps, float* ring, const float* tab, int kp, f32x16 (&acc)[BM / 64][BN / 64],
                                                AMeta (&meta)[Ring<BM, BN>::stages - 1], ALoad<BM / 32, ATr<AT>::two>& sa,
                                                BLoad<BN / 32>& sb, int base, int nsteps, int kchunks, int wave, int lane, int wm, int wn) {
         using L = Lds<BM, BN, AT>;
@@ -439,12 +449,12 @@ struct FusedLoop {
         if constexpr (K < PERIOD) {
             if (base + K < nsteps) {
                 constexpr int RS = (K + 1) % (S - 1);       // raw slot of step K + 1 (and then of step K + S)
-                pipe_step_fused<BM, BN, WT, F16, AT>(p, ring + ((K + 1) % 2) * L::A_STAGE, ring + L::B_OFF + ((K + S - 1) % S) * L::B_STAGE,
+                pipe_step_fused<BM, BN, WT, F16, AT>(p, taps, ring + ((K + 1) % 2) * L::A_STAGE, ring + L::B_OFF + ((K + S - 1) % S) * L::B_STAGE,
                                                      ring + L::RAW_OFF + RS * L::A_STAGE, ring + L::RAW2_OFF + RS * L::A_STAGE,
                                                      ring + (K % 2) * L::A_STAGE, ring + L::B_OFF + (K % S) * L::B_STAGE, tab, kp, acc,
                                                      meta[RS], sa, sb, nsteps, kchunks, wave, lane, wm, wn);
             }
-            FusedLoop<BM, BN, WT, F16, AT, K + 1>::run(p, ring, tab, kp, acc, meta, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
+            FusedLoop<BM, BN, WT, F16, AT, K + 1>::run(p, taps, ring, tab, kp, acc, meta, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
         }
     }
 };
@@ -524,13 +534,14 @@ __device__ __forceinline__ float4 shfl_xor4(float4 v, int o) {
     return make_float4(__shfl_xor(v.x, o), __shfl_xor(v.y, o), __shfl_xor(v.z, o), __shfl_xor(v.w, o));
 }
 
-template <int BM, int BN, bool WT, bool F16 = false, int AT = 0>
-__global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
+template <int BM, int BN, bool WT, bool F16, int AT>
+__device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, const int tile_id, const int slice) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int LA = BM / 32;                 // A chunks per lane per step (per source)
     using L = Lds<BM, BN, AT>;
     constexpr int STAGES = L::STAGES;
 
+    P3D_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* rowIdx = reinterpret_cast<int*>(smem);                           // [BM] output row of tile row r, -1 past M
     float* ring = reinterpret_cast<float*>(rowIdx + BM);                  // ring; the epilogue tile overlays it
@@ -542,10 +553,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
-    const long long M = (long long)p.N * p.Gd * p.Gh * p.Gw;
+    const long long M = (long long)p.N * geo.Gd * geo.Gh * geo.Gw;
     const int NT = (p.Nc + BN - 1) / BN;
     const int nsplit = p.nsplit;
-    const int tile_id = (int)blockIdx.x, slice = (int)blockIdx.y;      // block -> (output tile, K-slice)
+    const P3dTap* taps = geo.taps;
     const int nt = tile_id % NT;
     const int mt = tile_id / NT;
     const long long m0 = (long long)mt * BM;
@@ -558,16 +569,16 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
         const unsigned m = m0u + r;
         int ro = -1;
         if (m < Mu) {
-            const unsigned t1 = p3d_div(m, p.fGw), gw = m - t1 * (unsigned)p.Gw;
-            const unsigned t2 = p3d_div(t1, p.fGh), gh = t1 - t2 * (unsigned)p.Gh;
-            const unsigned n = p3d_div(t2, p.fGd), gd = t2 - n * (unsigned)p.Gd;
-            const int od = gd * p.osd + p.ood, oh = gh * p.osh + p.ooh, ow = gw * p.osw + p.oow;
+            const unsigned t1 = p3d_div(m, geo.fGw), gw = m - t1 * (unsigned)geo.Gw;
+            const unsigned t2 = p3d_div(t1, geo.fGh), gh = t1 - t2 * (unsigned)geo.Gh;
+            const unsigned n = p3d_div(t2, geo.fGd), gd = t2 - n * (unsigned)geo.Gd;
+            const int od = gd * p.osd + geo.ood, oh = gh * p.osh + geo.ooh, ow = gw * p.osw + geo.oow;
             ro = (((int)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
         }
         rowIdx[r] = ro;
     }
     // ---- this block's slice of the (tap, k-chunk) steps --------------------------------------------
-    const int total_steps = p.ntaps * kchunks;
+    const int total_steps = geo.ntaps * kchunks;
     const int per = (total_steps + nsplit - 1) / nsplit;
     const int s_begin = slice * per;
     const int s_end = min(total_steps, s_begin + per);
@@ -583,18 +594,18 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
 
     ALoad<LA, ATr<AT>::two> sa;
     BLoad<BN / 32> sb;
-    a_init<BM, ATr<AT>::two>(p, sa, m0u, Mu, wave, lane, s_begin, kchunks);
+    a_init<BM, ATr<AT>::two>(p, geo, sa, m0u, Mu, wave, lane, s_begin, kchunks);
     b_init<BN, WT>(p, sb, n0, wave, lane, s_begin, kchunks);
     if constexpr (AT == P3D_AT_NONE) {
         // prologue: STAGES-1 steps in flight; then step k computes from stage k % STAGES while refilling the stage
         // that was consumed one step earlier.  All stage addresses are compile-time constants (StepLoop).
 #pragma unroll
         for (int k = 0; k < STAGES - 1; ++k) {
-            issue_a_dma<BM>(p, ring + k * L::A_STAGE, sa, nsteps, kchunks, k == 0, wave, lane);
-            issue_b_dma<BN, WT>(p, ring + L::B_OFF + k * L::B_STAGE, sb, nsteps, kchunks, wave, lane);
+            issue_a_dma<BM>(p, taps, ring + k * L::A_STAGE, sa, nsteps, kchunks, k == 0, wave, lane);
+            issue_b_dma<BN, WT>(p, taps, ring + L::B_OFF + k * L::B_STAGE, sb, nsteps, kchunks, wave, lane);
         }
         for (int base = 0; base < nsteps; base += STAGES)
-            StepLoop<BM, BN, WT, F16, 0>::run(p, ring, acc, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
+            StepLoop<BM, BN, WT, F16, 0>::run(p, taps, ring, acc, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
     } else {
         // fused prologue, in the issue order the steady state has (pipe_step_fused's counted wait relies on it):
         //   A(0);  [A(1), B(0)]  (3-stage ring only);  the coefficient table (its loads queue behind those);  transform A(0);
@@ -602,10 +613,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
         AMeta meta[STAGES - 1];
         float* raw = ring + L::RAW_OFF;
         float* raw2 = ring + L::RAW2_OFF;
-        issue_a_raw<BM, AT>(p, raw, raw2, meta[0], sa, nsteps, kchunks, true, wave, lane);
+        issue_a_raw<BM, AT>(p, taps, raw, raw2, meta[0], sa, nsteps, kchunks, true, wave, lane);
         if constexpr (STAGES == 3) {
-            issue_a_raw<BM, AT>(p, raw + L::A_STAGE, raw2 + L::A_STAGE, meta[1], sa, nsteps, kchunks, false, wave, lane);
-            issue_b_dma<BN, WT>(p, ring + L::B_OFF, sb, nsteps, kchunks, wave, lane);
+            issue_a_raw<BM, AT>(p, taps, raw + L::A_STAGE, raw2 + L::A_STAGE, meta[1], sa, nsteps, kchunks, false, wave, lane);
+            issue_b_dma<BN, WT>(p, taps, ring + L::B_OFF, sb, nsteps, kchunks, wave, lane);
         }
         build_table<AT>(p, tab, kp, tile_id == 0 && slice == 0);
         wait_vmcnt<0>();
@@ -615,10 +626,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
             transform_load<BM, AT>(meta[0], raw, raw2, sa.achunk, tab, kp, xin, wave, lane);
             transform_store<BM, AT>(meta[0], xin, ring, wave, lane);
         }
-        issue_a_raw<BM, AT>(p, raw, raw2, meta[0], sa, nsteps, kchunks, false, wave, lane);
-        issue_b_dma<BN, WT>(p, ring + L::B_OFF + (STAGES - 2) * L::B_STAGE, sb, nsteps, kchunks, wave, lane);
+        issue_a_raw<BM, AT>(p, taps, raw, raw2, meta[0], sa, nsteps, kchunks, false, wave, lane);
+        issue_b_dma<BN, WT>(p, taps, ring + L::B_OFF + (STAGES - 2) * L::B_STAGE, sb, nsteps, kchunks, wave, lane);
         for (int base = 0; base < nsteps; base += STAGES * (STAGES - 1))
-            FusedLoop<BM, BN, WT, F16, AT, 0>::run(p, ring, tab, kp, acc, meta, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
+            FusedLoop<BM, BN, WT, F16, AT, 0>::run(p, taps, ring, tab, kp, acc, meta, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------
@@ -815,10 +826,32 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
             float t1 = sred[tid * 2], t2 = sred[tid * 2 + 1];
 #pragma unroll
             for (int g = 1; g < RG; ++g) { t1 += sred[(g * BN + tid) * 2]; t2 += sred[(g * BN + tid) * 2 + 1]; }
-            float* dst = p.statpart + ((size_t)(p.stat_base + mt) * p.Nc + n0 + tid) * 2;
+            float* dst = p.statpart + ((size_t)(geo.stat_base + mt) * p.Nc + n0 + tid) * 2;
             dst[0] = t1; dst[1] = t2;
         }
     }
+}
+
+template <int BM, int BN, bool WT, bool F16 = false, int AT = 0>
+__global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
+    Geo geo;
+    geo.Gd = p.Gd; geo.Gh = p.Gh; geo.Gw = p.Gw; geo.fGd = p.fGd; geo.fGh = p.fGh; geo.fGw = p.fGw;
+    geo.ood = p.ood; geo.ooh = p.ooh; geo.oow = p.oow; geo.stat_base = p.stat_base; geo.ntaps = p.ntaps; geo.taps = p.taps;
+    igemm2_body<BM, BN, WT, F16, AT>(p, geo, (int)blockIdx.x, (int)blockIdx.y);      // block -> (output tile, K-slice)
+}
+// One launch for the residue classes of a transposed conv / strided input gradient: block ranges per class, heaviest class
+// first (a class with eight taps runs eight times as long per tile as one with a single tap: the late blocks are the short ones)
+template <int BM, int BN, bool WT, bool F16 = false>
+__global__ __launch_bounds__(256) void igemm2_group_kernel(const IgemmGroupArgs g) {
+    int c = 0;
+#pragma unroll
+    for (int q = 1; q < P3D_IGEMM_CLASSES; ++q)
+        if (q < g.nclass && (int)blockIdx.x >= g.cls[q].blk0) c = q;
+    Geo geo;
+    geo.Gd = g.cls[c].Gd; geo.Gh = g.cls[c].Gh; geo.Gw = g.cls[c].Gw; geo.fGd = g.cls[c].fGd; geo.fGh = g.cls[c].fGh; geo.fGw = g.cls[c].fGw;
+    geo.ood = g.cls[c].ood; geo.ooh = g.cls[c].ooh; geo.oow = g.cls[c].oow; geo.stat_base = g.cls[c].stat_base; geo.ntaps = g.cls[c].ntaps;
+    geo.taps = g.cls[c].taps;
+    igemm2_body<BM, BN, WT, F16, 0>(g.common, geo, (int)blockIdx.x - g.cls[c].blk0, 0);
 }
 
 constexpr int MAX_TABLE_FLOATS = 4 * 2048;        // coefficient table: up to 4 coefficients x 2048 reduction channels
@@ -1002,4 +1035,85 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStr
     if (pl.bm == 128 && pl.bn == 128) return launch_t<128, 128>(a, pl, s);
     if (pl.bm == 128 && pl.bn == 64) return launch_t<128, 64>(a, pl, s);
     return launch_t<64, 64>(a, pl, s);
+}
+
+// ---- grouped launch of residue classes ---------------------------------------------------------------------------------
+bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& pl) {
+    if (n < 2 || n > P3D_IGEMM_CLASSES || pl.splits != 1) return false;
+    for (int i = 0; i < n; ++i) {
+        const IgemmArgs& a = v[i];
+        if (a.at_mode != P3D_AT_NONE || a.ngate || a.x != v[0].x || a.y != v[0].y || a.w != v[0].w || a.wT != v[0].wT || a.K != v[0].K ||
+            a.Nc != v[0].Nc || a.N != v[0].N || a.f16 != v[0].f16 || a.accum != v[0].accum || a.bias != v[0].bias || a.statpart != v[0].statpart)
+            return false;
+        const P3dIgemmPlan q = p3d_igemm2_plan(a, 1);
+        if (q.bm != pl.bm || q.bn != pl.bn || q.splits != 1) return false;
+    }
+    return true;
+}
+
+namespace {
+template <int BM, int BN>
+hipError_t launch_group_t(IgemmGroupArgs& g, const long long* tiles, hipStream_t s) {
+    long long blocks = 0;
+    for (int q = 0; q < g.nclass; ++q) { g.cls[q].blk0 = (int)blocks; blocks += tiles[q]; }
+    if (blocks <= 0 || blocks >= (1ll << 31)) return blocks <= 0 ? hipSuccess : hipErrorInvalidValue;
+    constexpr size_t sm = smem_fixed_bytes<BM, BN, 0>();
+    static std::once_flag once;
+    std::call_once(once, [] {
+        hipFuncSetAttribute((const void*)igemm2_group_kernel<BM, BN, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipFuncSetAttribute((const void*)igemm2_group_kernel<BM, BN, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipFuncSetAttribute((const void*)igemm2_group_kernel<BM, BN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipFuncSetAttribute((const void*)igemm2_group_kernel<BM, BN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    });
+    const dim3 grid((unsigned)blocks), blk(256);
+    const IgemmArgs& a = g.common;
+    if (a.f16) {
+        if (a.wT) hipLaunchKernelGGL((igemm2_group_kernel<BM, BN, true, true>), grid, blk, sm, s, g);
+        else hipLaunchKernelGGL((igemm2_group_kernel<BM, BN, false, true>), grid, blk, sm, s, g);
+    } else {
+        if (a.wT) hipLaunchKernelGGL((igemm2_group_kernel<BM, BN, true, false>), grid, blk, sm, s, g);
+        else hipLaunchKernelGGL((igemm2_group_kernel<BM, BN, false, false>), grid, blk, sm, s, g);
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan& pl, hipStream_t s) {
+    if (!p3d_igemm2_groupable(v, n, pl)) return hipErrorInvalidValue;
+    // the checks of the single launch, per class
+    for (int i = 0; i < n; ++i) {
+        const IgemmArgs& a = v[i];
+        const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
+        if (M >= (1ll << 31) || (long long)a.N * a.Di * a.Hi * a.Wi >= (1ll << 31) || (long long)a.N * a.Do * a.Ho * a.Wo >= (1ll << 31))
+            return hipErrorInvalidValue;
+        if (a.Gd * a.isd >= 1024 || a.Gh * a.ish >= 1024 || a.Gw * a.isw >= 1024 || a.ntaps > P3D_MAX_TAPS) return hipErrorInvalidValue;
+        if ((a.K & 3) || (a.ldx & 3) || !a.zeros || (a.Nc & 3) || (a.ldy & 3)) return hipErrorInvalidValue;
+    }
+    // heaviest class first
+    int order[P3D_IGEMM_CLASSES];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order, order + n, [&](int x, int y) { return v[x].ntaps > v[y].ntaps; });
+    IgemmGroupArgs g;
+    memset(&g, 0, sizeof(g));
+    g.common = v[0];
+    g.common.nsplit = 1; g.common.slab = nullptr; g.common.cnt = nullptr;
+    long long tiles[P3D_IGEMM_CLASSES];
+    int nc = 0;
+    for (int k = 0; k < n; ++k) {
+        const IgemmArgs& a = v[order[k]];
+        const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
+        if (M <= 0) continue;
+        IgemmClass& c = g.cls[nc];
+        c.Gd = a.Gd; c.Gh = a.Gh; c.Gw = a.Gw;
+        c.fGd = p3d_fastdiv((unsigned)a.Gd); c.fGh = p3d_fastdiv((unsigned)a.Gh); c.fGw = p3d_fastdiv((unsigned)a.Gw);
+        c.ood = a.ood; c.ooh = a.ooh; c.oow = a.oow; c.stat_base = a.stat_base; c.ntaps = a.ntaps;
+        for (int t = 0; t < a.ntaps; ++t) c.taps[t] = a.taps[t];
+        tiles[nc] = ((M + pl.bm - 1) / pl.bm) * ((a.Nc + pl.bn - 1) / pl.bn);
+        ++nc;
+    }
+    g.nclass = nc;
+    if (nc == 0) return hipSuccess;
+    if (pl.bm == 128 && pl.bn == 128) return launch_group_t<128, 128>(g, tiles, s);
+    if (pl.bm == 128 && pl.bn == 64) return launch_group_t<128, 64>(g, tiles, s);
+    return launch_group_t<64, 64>(g, tiles, s);
 }

@@ -50,6 +50,7 @@ __device__ __forceinline__ double fold16(double v) {
 // stores of the producer's epilogue, not atomics).
 template <int LPC>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(BnParams bn, double invM, int use_batch, int update_moving, float eps) {
+    P3D_CHAIN_PRIO();
     const int r = threadIdx.x % LPC;
     const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     const bool ok = c < bn.C;
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnParams bn, double in
 
 // Per-channel (sum, sumsq) of y.  Thread = one float4 channel group, RPI rows per block pass.  Block b writes partial b.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int ld, long long M, int C, float* statpart) {
+    P3D_CHAIN_PRIO();
     __shared__ float red[256][8];
     const int c4n = C >> 2;
     const int rpi = 256 / c4n;
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int ld, l
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
+    P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = a.M * c4n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -183,6 +186,7 @@ __device__ __forceinline__ void bn_fold64(const BnParams& bn, int c0, double inv
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_fold_apply_kernel(BnApplyArgs a, BnParams bn1, BnParams bn2, double invM, int batch1, int batch2,
                                                            int update_moving, float eps, int rows_per_block) {
+    P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 2 || MODE == 3);
     __shared__ __attribute__((aligned(16))) float sc1[64], sh1[64], sc2[64], sh2[64];
     const int c0 = blockIdx.y * 64;
@@ -233,6 +237,7 @@ __device__ __forceinline__ void bn_bwd_gates(const BnBwdArgs& a, long long row, 
 // Per-channel sums of g and g*xhat.  Thread = one float4 channel group, RPI rows per block pass.
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+    P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 2 || MODE == 3);
     __shared__ float red[256][TWO ? 16 : 8];
     const int c4n = a.C >> 2;
@@ -286,6 +291,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 // sum g*xhat / M) and the BN parameter gradients (each BN parameter is produced exactly once per step, so they are
 // written, not accumulated).
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int two) {
+    P3D_CHAIN_PRIO();
     const int r = threadIdx.x & 15;
     const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool ok = c < a.C;
@@ -315,6 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int t
 // Fused BatchNorm backward (conv_igemm2.hip, bn_grad_fold_channel) for MANY partials: 16 lanes per channel fold the gating
 // launch's per-tile (sum g, sum g*xhat) in a fixed order and publish k1 / k2 / k3 and the parameter gradients.
 __global__ __launch_bounds__(256) void bn_grad_finalize_kernel(BnGradFold f) {
+    P3D_CHAIN_PRIO();
     const int r = threadIdx.x & 15;
     const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool ok = c < f.C;
@@ -346,6 +353,7 @@ __device__ __forceinline__ void ldcoef(const float* coef, int c, float4& c1, flo
 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+    P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 2 || MODE == 3);
     const int c4n = a.C >> 2;
     const long long total = a.M * c4n;
@@ -388,6 +396,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolArgs a) {
+    P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * c4n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -426,6 +435,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolArgs a) {
 __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* pred, const float* target, long long n,
                                                         double* loss_out, float* dl, int through_sigmoid, double* part,
                                                         unsigned* counter) {
+    P3D_CHAIN_PRIO();
     __shared__ double wsum[4];
     __shared__ int last_flag;
     double acc = 0.0;
@@ -720,6 +730,7 @@ hipError_t p3d_maxpool_fwd(const PoolArgs& a, hipStream_t s) {
 // Non-overlapping windows (k == s, no padding: the temporal pools p3d.py:183,189,195): every input cell belongs to
 // exactly one window, so dx is written (or accumulated) directly -- no atomics, no zero fill.
 __global__ __launch_bounds__(256) void maxpool_bwd_disjoint_kernel(PoolArgs a, int accumulate) {
+    P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * c4n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -753,6 +764,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_disjoint_kernel(PoolArgs a, i
 // Overlapping windows (pool1, p3d.py:177: k = [2,3,3], s = 2): thread = one input cell x 4 channels; it visits the
 // windows that contain the cell (at most ceil(k/s) per axis) and takes dy where the stored arg-max tap is its own.
 __global__ __launch_bounds__(256) void maxpool_bwd_gather_kernel(PoolArgs a, int accumulate) {
+    P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = (long long)a.N * a.Di * a.Hi * a.Wi * c4n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {

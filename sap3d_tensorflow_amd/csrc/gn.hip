@@ -42,6 +42,7 @@ __device__ __forceinline__ float4 dropmask4(unsigned long long seed, long long e
 // ---- statistics: sums[n][c] += (sum, sumsq) over a slice of the sample's rows.  grid = (row slices, N).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* y, int ld, int R, int C, double* sums, float* part,
                                                        unsigned* counters) {
+    P3D_CHAIN_PRIO();
     __shared__ float red[256][8];
     __shared__ int last_flag;
     const int c4n = C >> 2, rpi = 256 / c4n;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* y, int ld, i
 
 // ---- finalize: thread per (n, c); the C/G (a power of two <= 32) lanes of a group fold with shuffles
 __global__ void gn_finalize_kernel(GnParams p, int N, int R, float eps) {
+    P3D_CHAIN_PRIO();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cg = p.C / p.G;
     const bool ok = i < N * p.C;
@@ -109,6 +111,7 @@ __global__ void gn_finalize_kernel(GnParams p, int N, int R, float eps) {
 // ---- apply
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
+    P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = a.M * c4n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -156,6 +159,7 @@ __device__ __forceinline__ void gn_gates(const GnApplyArgs& a, long long row, in
 // per-(n,c) sums of g and g*xhat over a slice of the sample's rows.  grid = (row slices, N)
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnApplyArgs a) {
+    P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 3);
     __shared__ float red[256][TWO ? 16 : 8];
     __shared__ int last_flag;
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnApplyArgs a) {
 
 // thread per (n, c): fold gamma-weighted sums over the group's lanes -> coefficients  dy = k*g - c1 - xhat*c2
 __global__ void gn_bwd_finalize_kernel(GnParams p, int N, int R) {
+    P3D_CHAIN_PRIO();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cg = p.C / p.G;
     const bool ok = i < N * p.C;
@@ -235,6 +240,7 @@ __global__ void gn_bwd_finalize_kernel(GnParams p, int N, int R) {
 }
 // thread per channel: dgamma = sum_n sum(g*xhat), dbeta = sum_n sum(g)
 __global__ void gn_bwd_params_kernel(GnParams p, int N, float* dgamma, float* dbeta) {
+    P3D_CHAIN_PRIO();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= p.C) return;
     double s1 = 0.0, s2 = 0.0;
@@ -256,6 +262,7 @@ __device__ __forceinline__ float4 gn_dx(const GnParams& g, long long t, float4 g
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnApplyArgs a) {
+    P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = a.M * c4n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -294,6 +301,7 @@ __device__ __forceinline__ float hsum4(float4 v) { return (v.x + v.y) + (v.z + v
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_small_fwd_kernel(GnApplyArgs a) {
+    P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 3);
     __shared__ float xch[4];
     const int cpg = a.C / a.g1.G, c4n = cpg >> 2, RL = 256 / c4n;
@@ -358,6 +366,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd_kernel(GnApplyArgs a) {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GnApplyArgs a) {
+    P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 3);
     __shared__ float4 red[256][TWO ? 4 : 2];
     __shared__ float coef[4];                       // c1, c2 of GN1 (and GN2)

@@ -16,6 +16,7 @@ namespace {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
+    P3D_CHAIN_PRIO();
     extern __shared__ float kw[];     // [27][C]
     const int C = a.C;
     for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) kw[i] = a.k[i];
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
 // xor-shuffles in a fixed order.
 template <int L>
 __global__ __launch_bounds__(256) void head_fwd_lanes_kernel(HeadArgs a) {
+    P3D_CHAIN_PRIO();
     extern __shared__ float kw[];     // [27][C]
     const int C = a.C;
     for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) kw[i] = a.k[i];
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256) void head_fwd_lanes_kernel(HeadArgs a) {
 }
 
 __global__ __launch_bounds__(256) void head_bwd_input_kernel(HeadArgs a) {
+    P3D_CHAIN_PRIO();
     extern __shared__ float kw[];
     const int C = a.C, c4n = C >> 2;
     for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) kw[i] = a.k[i];
@@ -309,6 +312,7 @@ __global__ __launch_bounds__(256) void head_bwd_filter4_kernel(HeadArgs a) {
 // ---- tf.layers.conv3d(x, 1, 3, 1, 'same') head of the GN decoder-block network (gn/p3d_gn.py:537): the same
 // Cout = 1 stencil at stride 1, SAME padding 1 on every side.  logits[o] = bias + sum_k <x[o+k-1,:], K[k,:,0]>.
 __global__ __launch_bounds__(256) void headc_fwd_kernel(HeadArgs a) {
+    P3D_CHAIN_PRIO();
     extern __shared__ float kw[];     // [27][C]
     const int C = a.C;
     for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) kw[i] = a.k[i];
@@ -346,6 +350,7 @@ __global__ __launch_bounds__(256) void headc_fwd_kernel(HeadArgs a) {
 
 // dx[i,c] = sum_k dlogits[i-k+1] * K[k,c]
 __global__ __launch_bounds__(256) void headc_bwd_input_kernel(HeadArgs a) {
+    P3D_CHAIN_PRIO();
     extern __shared__ float kw[];
     const int C = a.C, c4n = C >> 2;
     for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) kw[i] = a.k[i];

@@ -223,6 +223,31 @@ void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld
                      const StatSink* stats, hipEvent_t fork = nullptr, hipEvent_t join = nullptr) {
     (void)out; (void)ld; (void)rows; (void)C;
     int base = 0;
+    for (auto& a : v) {
+        a.accum = accumulate ? 1 : 0;
+        a.statpart = nullptr; a.stat_base = 0;
+        a.zeros = g_zero_page;
+        if (stats && stats->part) {
+            const P3dIgemmPlan pl = p3d_igemm2_plan(a, 1);
+            const int mt = p3d_igemm2_mtiles(a, pl);
+            if (base + mt > stats->cap) throw P3dError("statistics partials overflow their arena slot");
+            a.statpart = stats->part; a.stat_base = base;
+            base += mt;
+        }
+    }
+    // residue classes that share a plan go out as ONE launch (conv_igemm2.hip, igemm2_group_kernel): a class alone leaves
+    // CUs idle (deconv3 at 8 clips: 196 tiles of 128x128 per class), all of them together fill the chip in a few waves
+    if (v.size() >= 2 && !c.dry) {
+        const P3dIgemmPlan pl = p3d_igemm2_plan(v[0], 1);
+        if (p3d_igemm2_groupable(v.data(), (int)v.size(), pl)) {
+            double fl = 0, by = 0;
+            for (auto& a : v) { double f1, b1; igemm_work(a, f1, b1); fl += f1; by += b1; }
+            const char* name = pl.bm == 128 ? (pl.bn == 128 ? "igemm2_group_kernel<128,128>" : "igemm2_group_kernel<128,64>") : "igemm2_group_kernel<64,64>";
+            launch(c, name, fl, by, [&]() { return p3d_launch_igemm2_group(v.data(), (int)v.size(), pl, c.s); });
+            if (stats && stats->nparts) *stats->nparts = base;
+            return;
+        }
+    }
     const bool spread = fork && join && c.side && !c.dry && !c.prof && v.size() >= 4;
     Ctx sc = c;
     if (spread) {
@@ -232,16 +257,6 @@ void run_igemm_group(const Ctx& c, std::vector<IgemmArgs>& v, float* out, int ld
     }
     int index = 0;
     for (auto& a : v) {
-        a.accum = accumulate ? 1 : 0;
-        a.statpart = nullptr; a.stat_base = 0;
-        if (stats && stats->part) {
-            IgemmArgs t = a; t.zeros = g_zero_page;
-            const P3dIgemmPlan pl = p3d_igemm2_plan(t, 1);
-            const int mt = p3d_igemm2_mtiles(t, pl);
-            if (base + mt > stats->cap) throw P3dError("statistics partials overflow their arena slot");
-            a.statpart = stats->part; a.stat_base = base;
-            base += mt;
-        }
         launch_igemm((spread && (index & 1)) ? sc : c, a, 1);
         ++index;
     }

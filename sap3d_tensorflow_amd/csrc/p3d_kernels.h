@@ -50,6 +50,14 @@ inline P3dFastDiv p3d_fastdiv(unsigned d) {
 __device__ __forceinline__ unsigned p3d_div(unsigned n, P3dFastDiv f) { return f.mul ? (__umulhi(n, f.mul) >> f.shift) : n; }
 #endif
 
+// Wave priority of the kernels on the latency-bound main-stream chain.  The filter-gradient kernels that share the chip with
+// them from the side stream stay at priority 0, so a SIMD that hosts both issues the chain's instructions first: the chain
+// is what the step waits for, the filter gradients only have to be done by the end (measured: 17.13 -> 16.66 ms per step,
+// priority 1 and 3 alike; profiles/r03_prio_ab.json).
+#if defined(__HIPCC__)
+#define P3D_CHAIN_PRIO() __builtin_amdgcn_s_setprio(2)
+#endif
+
 struct P3dTap {
     int16_t dd, dh, dw;   // gathered coordinate = g*is + d{d,h,w}
     int16_t widx;         // which [K][N] slab of the weight tensor
@@ -132,6 +140,25 @@ struct IgemmArgs {
     P3dTap taps[P3D_MAX_TAPS];
 };
 
+// What differs between the launches of one group -- the residue classes of a transposed conv / of a strided conv's input
+// gradient: iteration grid, output offset, kernel taps.  One grouped launch carries all of them (p3d_launch_igemm2_group):
+// a class alone offers too few tiles for 256 CUs (deconv3 at 8 clips: 196 tiles of 128x128 per class, eight classes).
+#define P3D_IGEMM_CLASSES 8
+struct IgemmClass {
+    int Gd, Gh, Gw;
+    P3dFastDiv fGd, fGh, fGw;
+    int ood, ooh, oow;
+    int stat_base;        // first statistics partial of this class (its m tiles follow each other)
+    int ntaps;
+    int blk0;             // first block of this class in the grouped launch (classes in descending order of work)
+    P3dTap taps[P3D_MAX_TAPS];
+};
+struct IgemmGroupArgs {
+    IgemmArgs common;     // everything the classes share (its own grid / offsets / taps are unused)
+    int nclass;
+    IgemmClass cls[P3D_IGEMM_CLASSES];
+};
+
 // Tile and split-K choice of the pipelined kernel (conv_igemm2.hip)
 struct P3dIgemmPlan {
     int bm = 64, bn = 64, splits = 1;
@@ -183,6 +210,10 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split);
 void p3d_tune_begin(hipStream_t s);
 void p3d_tune_end();
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipStream_t s);
+// n launches that differ only in what IgemmClass holds, as ONE launch (no K-slices, no operand transform / gates; n <= 8).
+// stat_base of every class must be set by the caller (statistics partials of class q start at its stat_base).
+bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& plan);
+hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan& plan, hipStream_t s);
 void p3d_igemm2_override(int tile, int splits);   // test / tools hook: force the tile (0: 64x64, 1: 128x64, 2: 128x128) and the K-slice count; -1 / 0 = no override
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s);   // up to P3D_WGRAD_GROUP problems, one launch
