@@ -88,6 +88,7 @@ struct BLoad {
     int bk[LB];              // WT: 4 * logical chunk; !WT: k row within the step
     bool bok[LB];            // n inside Nc
     int t, kc, issued;
+    const float* w;          // weight tensor of this launch / class
 };
 
 // The per-class part of a launch as the kernel body sees it: from the kernel arguments themselves (one class) or from the
@@ -97,6 +98,7 @@ struct Geo {
     P3dFastDiv fGd, fGh, fGw;
     int ood, ooh, oow, stat_base, ntaps;
     const P3dTap* taps;
+    const float* w; const float* bias; float* y; float* statpart;      // a grouped launch may also carry sibling convs (ST_B)
 };
 
 template <int BM, bool TWO>
@@ -122,8 +124,9 @@ __device__ __forceinline__ void a_init(const IgemmArgs& p, const Geo& geo, ALoad
     st.t = s_begin / kchunks; st.kc = s_begin - st.t * kchunks; st.issued = 0;
 }
 template <int BN, bool WT>
-__device__ __forceinline__ void b_init(const IgemmArgs& p, BLoad<BN / 32>& st, int n0, int wave, int lane, int s_begin, int kchunks) {
+__device__ __forceinline__ void b_init(const IgemmArgs& p, const float* w, BLoad<BN / 32>& st, int n0, int wave, int lane, int s_begin, int kchunks) {
     constexpr int LB = BN / 32;
+    st.w = w;
     const int a_slot = lane & 7, a_sub = lane >> 3;
     if (!WT) {
         constexpr int LANES_PER_ROW = BN / 4, ROWS_PER_PIECE = 64 / LANES_PER_ROW;
@@ -182,11 +185,12 @@ __device__ __forceinline__ void issue_a_dma(const IgemmArgs& p, const P3dTap* ta
 template <int BN, bool WT>
 __device__ __forceinline__ void issue_b_dma(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ b_dst, BLoad<BN / 32>& st, int nsteps, int kchunks,
                                             int wave, int lane) {
+    // (the weight base travels in the loader state: per class in a grouped launch)
     constexpr int LB = BN / 32;
     const bool live = st.issued < nsteps;
     const int k0 = st.kc * BK;
     const float* zp = p.zeros + 4 * (lane & 7);
-    const float* wt = p.w + (long long)taps[live ? st.t : 0].widx * p.K * p.Nc;
+    const float* wt = st.w + (long long)taps[live ? st.t : 0].widx * p.K * p.Nc;
     if (!WT) {
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
@@ -595,7 +599,7 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
     ALoad<LA, ATr<AT>::two> sa;
     BLoad<BN / 32> sb;
     a_init<BM, ATr<AT>::two>(p, geo, sa, m0u, Mu, wave, lane, s_begin, kchunks);
-    b_init<BN, WT>(p, sb, n0, wave, lane, s_begin, kchunks);
+    b_init<BN, WT>(p, geo.w, sb, n0, wave, lane, s_begin, kchunks);
     if constexpr (AT == P3D_AT_NONE) {
         // prologue: STAGES-1 steps in flight; then step k computes from stage k % STAGES while refilling the stage
         // that was consumed one step earlier.  All stage addresses are compile-time constants (StepLoop).
@@ -743,15 +747,15 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
             }
         }
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
+        if (geo.bias && cok) bias4 = *reinterpret_cast<const float4*>(geo.bias + col);
 #pragma unroll 2
         for (int r = tid / F4R; r < BM; r += 256 / F4R) {
             const int ro = rowIdx[r];
             if (ro < 0 || !cok) continue;
             float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
             v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-            if (p.accum) { const float4 o = *reinterpret_cast<const float4*>(p.y + (long long)ro * p.ldy + col); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-            if (p.raw_store) *reinterpret_cast<float4*>(p.y + (long long)ro * p.ldy + col) = v;
+            if (p.accum) { const float4 o = *reinterpret_cast<const float4*>(geo.y + (long long)ro * p.ldy + col); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (p.raw_store) *reinterpret_cast<float4*>(geo.y + (long long)ro * p.ldy + col) = v;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 if (q >= p.ngate) break;
@@ -797,7 +801,7 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
 
     // -- output rows: bias, optional accumulate, row-wise float4 stores; the stored values go back to the tile for the
     //    statistics pass --------------------------------------------------------------------------------------------
-    const bool want_stats = p.statpart != nullptr;
+    const bool want_stats = geo.statpart != nullptr;
 #pragma unroll 4
     for (int i = tid; i < BM * F4R; i += 256) {
         const int r = i / F4R, c4 = (i - r * F4R) * 4;
@@ -805,9 +809,9 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
         const int col = n0 + c4;
         if (ro < 0 || col >= p.Nc) continue;
         float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
-        if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (geo.bias) { const float4 b = *reinterpret_cast<const float4*>(geo.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         if (want_stats) *reinterpret_cast<float4*>(tile + r * LDT + c4) = v;
-        float* dst = p.y + (long long)ro * p.ldy + col;
+        float* dst = geo.y + (long long)ro * p.ldy + col;
         if (p.accum) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *reinterpret_cast<float4*>(dst) = v;
     }
@@ -826,7 +830,7 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
             float t1 = sred[tid * 2], t2 = sred[tid * 2 + 1];
 #pragma unroll
             for (int g = 1; g < RG; ++g) { t1 += sred[(g * BN + tid) * 2]; t2 += sred[(g * BN + tid) * 2 + 1]; }
-            float* dst = p.statpart + ((size_t)(geo.stat_base + mt) * p.Nc + n0 + tid) * 2;
+            float* dst = geo.statpart + ((size_t)(geo.stat_base + mt) * p.Nc + n0 + tid) * 2;
             dst[0] = t1; dst[1] = t2;
         }
     }
@@ -837,6 +841,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     Geo geo;
     geo.Gd = p.Gd; geo.Gh = p.Gh; geo.Gw = p.Gw; geo.fGd = p.fGd; geo.fGh = p.fGh; geo.fGw = p.fGw;
     geo.ood = p.ood; geo.ooh = p.ooh; geo.oow = p.oow; geo.stat_base = p.stat_base; geo.ntaps = p.ntaps; geo.taps = p.taps;
+    geo.w = p.w; geo.bias = p.bias; geo.y = p.y; geo.statpart = p.statpart;
     igemm2_body<BM, BN, WT, F16, AT>(p, geo, (int)blockIdx.x, (int)blockIdx.y);      // block -> (output tile, K-slice)
 }
 // One launch for the residue classes of a transposed conv / strided input gradient: block ranges per class, heaviest class
@@ -851,6 +856,7 @@ __global__ __launch_bounds__(256) void igemm2_group_kernel(const IgemmGroupArgs 
     geo.Gd = g.cls[c].Gd; geo.Gh = g.cls[c].Gh; geo.Gw = g.cls[c].Gw; geo.fGd = g.cls[c].fGd; geo.fGh = g.cls[c].fGh; geo.fGw = g.cls[c].fGw;
     geo.ood = g.cls[c].ood; geo.ooh = g.cls[c].ooh; geo.oow = g.cls[c].oow; geo.stat_base = g.cls[c].stat_base; geo.ntaps = g.cls[c].ntaps;
     geo.taps = g.cls[c].taps;
+    geo.w = g.cls[c].w; geo.bias = g.cls[c].bias; geo.y = g.cls[c].y; geo.statpart = g.cls[c].statpart;
     igemm2_body<BM, BN, WT, F16, 0>(g.common, geo, (int)blockIdx.x - g.cls[c].blk0, 0);
 }
 
@@ -1042,8 +1048,11 @@ bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& pl) {
     if (n < 2 || n > P3D_IGEMM_CLASSES || pl.splits != 1) return false;
     for (int i = 0; i < n; ++i) {
         const IgemmArgs& a = v[i];
-        if (a.at_mode != P3D_AT_NONE || a.ngate || a.x != v[0].x || a.y != v[0].y || a.w != v[0].w || a.wT != v[0].wT || a.K != v[0].K ||
-            a.Nc != v[0].Nc || a.N != v[0].N || a.f16 != v[0].f16 || a.accum != v[0].accum || a.bias != v[0].bias || a.statpart != v[0].statpart)
+        // shared: the gathered operand and every extent / stride; per class: grid, offsets, taps, weights, bias, output, statistics
+        if (a.at_mode != P3D_AT_NONE || a.ngate || a.x != v[0].x || a.wT != v[0].wT || a.K != v[0].K || a.Nc != v[0].Nc || a.N != v[0].N ||
+            a.f16 != v[0].f16 || a.accum != v[0].accum || a.ldx != v[0].ldx || a.ldy != v[0].ldy || a.Di != v[0].Di || a.Hi != v[0].Hi ||
+            a.Wi != v[0].Wi || a.Do != v[0].Do || a.Ho != v[0].Ho || a.Wo != v[0].Wo || a.isd != v[0].isd || a.ish != v[0].ish ||
+            a.isw != v[0].isw || a.osd != v[0].osd || a.osh != v[0].osh || a.osw != v[0].osw)
             return false;
         const P3dIgemmPlan q = p3d_igemm2_plan(a, 1);
         if (q.bm != pl.bm || q.bn != pl.bn || q.splits != 1) return false;
@@ -1107,6 +1116,7 @@ hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan
         c.Gd = a.Gd; c.Gh = a.Gh; c.Gw = a.Gw;
         c.fGd = p3d_fastdiv((unsigned)a.Gd); c.fGh = p3d_fastdiv((unsigned)a.Gh); c.fGw = p3d_fastdiv((unsigned)a.Gw);
         c.ood = a.ood; c.ooh = a.ooh; c.oow = a.oow; c.stat_base = a.stat_base; c.ntaps = a.ntaps;
+        c.w = a.w; c.bias = a.bias; c.y = a.y; c.statpart = a.statpart;
         for (int t = 0; t < a.ntaps; ++t) c.taps[t] = a.taps[t];
         tiles[nc] = ((M + pl.bm - 1) / pl.bm) * ((a.Nc + pl.bn - 1) / pl.bn);
         ++nc;

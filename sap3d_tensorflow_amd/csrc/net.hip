@@ -848,10 +848,12 @@ struct p3d_handle {
         return g;
     }
 
+    std::vector<IgemmArgs> sib_pending;      // a sibling pair's first launch, waiting for the second (conv(): sibling)
+
     // ---- graph ops ---------------------------------------------------------------------------
     // tf.nn.conv3d / tf.layers.conv3d: SAME conv, optional bias, optional BN-statistics epilogue.
     Act* conv(const std::string& opname, Act* x, Param* w, Param* bias, const int k[3], const int s[3], int Cout, BN* bn,
-              const std::string& out_name, bool stem = false, bool bn_has_dropout = false, bool fwd_on_side = false,
+              const std::string& out_name, bool stem = false, bool bn_has_dropout = false, int sibling = 0,
               const ConvFuse* fuse = nullptr) {
         const ConvGeo g = make_geo(x->D, x->H, x->W, k, s);
         Act* y = new_act(out_name, x->N, g.O[0], g.O[1], g.O[2], Cout);
@@ -902,6 +904,19 @@ struct p3d_handle {
             ops.push_back(op);
             return y;
         }
+        // sibling convs on one input (ST_B: convS and convT both read relu(bn1(.)), p3d.py:65-72): the first one only prepares
+        // its launch, the second sends both out as ONE grouped launch (conv_igemm2.hip, igemm2_group_kernel) -- either alone
+        // leaves most CUs idle, and forking one to the side stream costs ~10 us of cross-stream latency each way
+        auto sibling_prepare = [=](const Ctx& c, IgemmArgs& a) {
+            a.zeros = g_zero_page; a.accum = 0; a.statpart = nullptr; a.stat_base = 0;
+            BN* sbn = bn ? ((c.fuse && cf.out_bn) ? bn : stats_target(bn, y->rows(), Cout, bn_has_dropout)) : nullptr;
+            if (sbn) {
+                const StatSink sink = bn_sink(sbn);
+                const int mt = p3d_igemm2_mtiles(a, p3d_igemm2_plan(a, 1));
+                if (mt > sink.cap) throw P3dError("statistics partials overflow their arena slot");
+                a.statpart = sink.part; *sink.nparts = mt;
+            }
+        };
         auto fwd_body = [=](const Ctx& c) {
             const bool fz = c.fuse && cf.at != 0;
             // fused: the A operand is the raw output of the conv before the BatchNorm (src[0].y), normalised on the fly
@@ -920,13 +935,29 @@ struct p3d_handle {
             StatSink sink; if (sbn) sink = bn_sink(sbn);
             run_igemm_group(c, v, y->p, y->ld, y->rows(), Cout, false, sbn ? &sink : nullptr);
         };
-        // fwd_on_side: this conv has a sibling that reads the same input (ST_B, p3d.py:65-72); it runs on the side
-        // stream next to it and the caller joins the streams (join_side) before their outputs are combined
-        hipEvent_t fork_fwd = fwd_on_side ? new_fork_event() : nullptr;
+        // sibling = 1 / 2: first / second of two convs that read the same input (ST_B, p3d.py:65-72)
+        hipEvent_t fork_fwd = nullptr;
         op.fwd = [=](const Ctx& c) {
             if (c.fuse && cf.at) fused_prefinalize(c, cf, cf.src[0].y->rows());      // on the main stream, ahead of a fork
-            if (fwd_on_side && c.side && !c.dry) on_side_stream(c, fork_fwd, fwd_body);
-            else fwd_body(c);
+            (void)fork_fwd;
+            if (sibling && !c.dry && !(c.fuse && cf.at) && ntap > 0 && !stem) {
+                IgemmArgs a = igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr, 0, false);
+                sibling_prepare(c, a);
+                if (sibling == 1) { sib_pending.push_back(a); return; }       // first of the pair: wait for the second
+                sib_pending.push_back(a);
+                std::vector<IgemmArgs> v;
+                v.swap(sib_pending);
+                const P3dIgemmPlan pl = p3d_igemm2_plan(v[0], 1);
+                if (p3d_igemm2_groupable(v.data(), (int)v.size(), pl)) {
+                    double fl = 0, by = 0;
+                    for (auto& q : v) { double f1, b1; igemm_work(q, f1, b1); fl += f1; by += b1; }
+                    launch(c, "igemm2_group_kernel<64,64>(siblings)", fl, by, [&]() { return p3d_launch_igemm2_group(v.data(), (int)v.size(), pl, c.s); });
+                } else {
+                    for (auto& q : v) launch_igemm(c, q, 1);
+                }
+                return;
+            }
+            fwd_body(c);
         };
         op.bwd = [=](const Ctx& c) {
             if (!(c.fuse_bwd && cf.any())) {
@@ -1005,20 +1036,6 @@ struct p3d_handle {
         };
         ops.push_back(op);
         return y;
-    }
-
-    // main stream waits for everything queued on the side stream so far (forward only; see conv(fwd_on_side))
-    void join_side(const std::string& opname) {
-        Op op;
-        op.name = opname; op.kind = "join";
-        hipEvent_t ev = new_fork_event();
-        op.fwd = [=](const Ctx& c) {
-            if (!c.side || c.dry) return;
-            HIPCHECK(hipEventRecord(ev, c.side));
-            HIPCHECK(hipStreamWaitEvent(c.s, ev, 0));
-        };
-        op.bwd = [](const Ctx&) {};
-        ops.push_back(op);
     }
 
     // tf.layers.conv3d_transpose(x, filters, k, s, 'same'): kernel [kd,kh,kw,Cout,Cin].
@@ -1602,7 +1619,7 @@ struct p3d_handle {
         const ConvGeo g1 = make_geo(x->D, x->H, x->W, one, s);
         const bool fz = (int64_t)x->N * g1.O[0] * g1.O[1] * g1.O[2] <= fuse_max_rows;      // this bottleneck is built fusable
         ConvFuse f1; if (fz) f1.out_bn = bn1;
-        Act* y1 = conv(B + "conv1", x, w1, nullptr, one, s, planes, bn1, "", false, false, false, &f1);
+        Act* y1 = conv(B + "conv1", x, w1, nullptr, one, s, planes, bn1, "", false, false, 0, &f1);
         Act* z1 = bn_apply(B + "bn1", 0, y1, bn1, nullptr, nullptr, nullptr, B + "conv1_bn_relu", false, /*fused_site=*/fz);
         const std::string nm = std::string("ST") + st + "_" + sid + "_2";
         Act* stout = nullptr;
@@ -1613,14 +1630,14 @@ struct p3d_handle {
             BN* bnS = add_bn("", planes, false);
             ConvFuse fS; fS.at = P3D_AT_RELU1; fS.src[0] = {y1, bn1, 1}; fS.ngate = 1; fS.gate[0] = {y1, bn1, 0}; fS.out_bn = bnS;
             if (!fz) fS = ConvFuse();
-            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, false, &fS);
+            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, 0, &fS);
             Act* zS = bn_apply(B + "bnS", 0, yS, bnS, nullptr, nullptr, nullptr, "", false, fz);
             Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
             Param* bT = conv_weight(nm + "_T_bias", {planes});
             BN* bnT = add_bn("", planes, false);
             ConvFuse fT; fT.at = P3D_AT_RELU1; fT.src[0] = {yS, bnS, 1}; fT.ngate = 1; fT.gate[0] = {yS, bnS, 0}; fT.out_bn = bnT;
             if (!fz) fT = ConvFuse();
-            Act* yT = conv(B + "convT", zS, wT, bT, kT, one, planes, bnT, "", false, false, false, &fT);
+            Act* yT = conv(B + "convT", zS, wT, bT, kT, one, planes, bnT, "", false, false, 0, &fT);
             stout = bn_apply(B + "bnT", 0, yT, bnT, nullptr, nullptr, nullptr, B + "st", false, fz);
             f3.at = P3D_AT_RELU1; f3.src[0] = {yT, bnT, 1}; f3.ngate = 1; f3.gate[0] = {yT, bnT, 0};
         } else if (st == 'B') {   // p3d.py:65-72
@@ -1631,14 +1648,13 @@ struct p3d_handle {
             // in the backward, adds the raw gradient convT left in z1->g, gates it and reduces for bn1
             ConvFuse fS; fS.at = P3D_AT_RELU1; fS.src[0] = {y1, bn1, 1}; fS.ngate = 1; fS.gate[0] = {y1, bn1, 0}; fS.accum_in = true; fS.out_bn = bnS;
             if (!fz) fS = ConvFuse();
-            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, /*fwd_on_side=*/true, &fS);
+            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, /*sibling=*/1, &fS);
             Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
             Param* bT = conv_weight(nm + "_T_bias", {planes});
             BN* bnT = add_bn("", planes, false);
             ConvFuse fT; fT.at = P3D_AT_RELU1; fT.src[0] = {y1, bn1, 2}; fT.out_bn = bnT;
             if (!fz) fT = ConvFuse();
-            Act* yT = conv(B + "convT", z1, wT, bT, kT, one, planes, bnT, "", false, false, false, &fT);
-            join_side(B + "joinST");
+            Act* yT = conv(B + "convT", z1, wT, bT, kT, one, planes, bnT, "", false, false, /*sibling=*/2, &fT);
             stout = bn_apply(B + "bnST", 3, yS, bnS, yT, bnT, nullptr, B + "st", false, fz);
             f3.at = P3D_AT_RELU2; f3.src[0] = {yS, bnS, 1}; f3.src[1] = {yT, bnT, 1};
             f3.ngate = 2; f3.gate[0] = {yS, bnS, 0}; f3.gate[1] = {yT, bnT, 0};
@@ -1648,7 +1664,7 @@ struct p3d_handle {
             BN* bnS = add_bn("", planes, false);
             ConvFuse fS; fS.at = P3D_AT_RELU1; fS.src[0] = {y1, bn1, 1}; fS.ngate = 1; fS.gate[0] = {y1, bn1, 0}; fS.out_bn = bnS;
             if (!fz) fS = ConvFuse();
-            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, false, &fS);
+            Act* yS = conv(B + "convS", z1, wS, bS, kS, one, planes, bnS, "", false, false, 0, &fS);
             Act* zS = bn_apply(B + "bnS", 0, yS, bnS, nullptr, nullptr, nullptr, "", false, fz);
             Param* wT = conv_weight(nm + "_T", {3, 1, 1, planes, planes});
             Param* bT = conv_weight(nm + "_T_bias", {planes});
@@ -1657,7 +1673,7 @@ struct p3d_handle {
             // own, gates and reduces for bnS
             ConvFuse fT; fT.at = P3D_AT_RELU1; fT.src[0] = {yS, bnS, 1}; fT.ngate = 1; fT.gate[0] = {yS, bnS, 0}; fT.accum_in = true; fT.out_bn = bnT;
             if (!fz) fT = ConvFuse();
-            Act* yT = conv(B + "convT", zS, wT, bT, kT, one, planes, bnT, "", false, false, false, &fT);
+            Act* yT = conv(B + "convT", zS, wT, bT, kT, one, planes, bnT, "", false, false, 0, &fT);
             stout = bn_apply(B + "bnT", 4, yT, bnT, zS, nullptr, nullptr, B + "st", false, fz);
             f3.at = P3D_AT_RELU2; f3.src[0] = {yS, bnS, 0}; f3.src[1] = {yT, bnT, 1};
             f3.ngate = 1; f3.gate[0] = {yT, bnT, 0}; f3.raw = zS; f3.raw_flag = zS->last_flag;      // the flag of bnT's skip read
@@ -1665,7 +1681,7 @@ struct p3d_handle {
         if (!fz) f3 = ConvFuse();
         Param* w3 = conv_weight("conv3_" + sid + "_3", {1, 1, 1, planes, planes * 4});
         BN* bn3 = add_bn("", planes * 4, false);
-        Act* y3 = conv(B + "conv3", stout, w3, nullptr, one, one, planes * 4, bn3, "", false, false, false, &f3);
+        Act* y3 = conv(B + "conv3", stout, w3, nullptr, one, one, planes * 4, bn3, "", false, false, 0, &f3);
         if (first) {              // p3d.py:124-127
             Param* wp = conv_weight("dw3d_" + sid, {1, 1, 1, inplanes, planes * 4});
             BN* bnp = add_bn("", planes * 4, false);

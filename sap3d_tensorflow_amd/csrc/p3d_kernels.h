@@ -151,6 +151,7 @@ struct IgemmClass {
     int stat_base;        // first statistics partial of this class (its m tiles follow each other)
     int ntaps;
     int blk0;             // first block of this class in the grouped launch (classes in descending order of work)
+    const float* w; const float* bias; float* y; float* statpart;      // per class as well: sibling convs on one input (ST_B)
     P3dTap taps[P3D_MAX_TAPS];
 };
 struct IgemmGroupArgs {
