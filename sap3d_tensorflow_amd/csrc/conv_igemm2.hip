@@ -99,6 +99,7 @@ struct Geo {
     int ood, ooh, oow, stat_base, ntaps;
     const P3dTap* taps;
     const float* w; const float* bias; float* y; float* statpart;      // a grouped launch may also carry sibling convs (ST_B)
+    int nsplit; float* slab; unsigned* cnt;                             // K-slices of this launch / class and their scratch
 };
 
 template <int BM, bool TWO>
@@ -559,7 +560,7 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
 
     const long long M = (long long)p.N * geo.Gd * geo.Gh * geo.Gw;
     const int NT = (p.Nc + BN - 1) / BN;
-    const int nsplit = p.nsplit;
+    const int nsplit = geo.nsplit;
     const P3dTap* taps = geo.taps;
     const int nt = tile_id % NT;
     const int mt = tile_id / NT;
@@ -663,7 +664,7 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
         // Slab stores are WRITE-THROUGH (sc1): they need no release fence (whose L2 write-back costs 2-6 us per block);
         // every storing wave drains its stores, the block meets at a barrier, one lane takes the ticket
         // (cdna_hip_programming.md Guideline 16, recipe R1).
-        float* myslab = p.slab + ((size_t)tile_id * nsplit + slice) * (BM * BN);
+        float* myslab = geo.slab + ((size_t)tile_id * nsplit + slice) * (BM * BN);
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(myslab, 0, BM * BN * 4, 0x00020000);
 #pragma unroll 4
         for (int i = tid; i < BM * F4R; i += 256) {
@@ -675,18 +676,18 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
         wait_vmcnt<0>();                                        // every storing wave drains its stores ...
         __syncthreads();
         if (tid == 0) {
-            const unsigned ticket = __hip_atomic_fetch_add(p.cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned ticket = __hip_atomic_fetch_add(geo.cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = ticket == (unsigned)(nsplit - 1);
             if (last) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale lines before the plain slab loads
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                p.cnt[tile_id] = 0;                             // ready for the next launch that uses this scratch
+                geo.cnt[tile_id] = 0;                           // ready for the next launch that uses this scratch
             }
             *flag = last;
         }
         __syncthreads();
         if (!*flag) return;
-        const float* slabs = p.slab + (size_t)tile_id * nsplit * (BM * BN);
+        const float* slabs = geo.slab + (size_t)tile_id * nsplit * (BM * BN);
         // The slabs come from other CUs' write-through stores: every load is a long-latency miss, so keep 16 of them in
         // flight per lane (4 tile positions x 4 slices) and add in slice order.
         constexpr int PER_LANE = BM * F4R / 256;                // float4 positions per lane: 4 / 8 / 16
@@ -842,6 +843,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     geo.Gd = p.Gd; geo.Gh = p.Gh; geo.Gw = p.Gw; geo.fGd = p.fGd; geo.fGh = p.fGh; geo.fGw = p.fGw;
     geo.ood = p.ood; geo.ooh = p.ooh; geo.oow = p.oow; geo.stat_base = p.stat_base; geo.ntaps = p.ntaps; geo.taps = p.taps;
     geo.w = p.w; geo.bias = p.bias; geo.y = p.y; geo.statpart = p.statpart;
+    geo.nsplit = p.nsplit; geo.slab = p.slab; geo.cnt = p.cnt;
     igemm2_body<BM, BN, WT, F16, AT>(p, geo, (int)blockIdx.x, (int)blockIdx.y);      // block -> (output tile, K-slice)
 }
 // One launch for the residue classes of a transposed conv / strided input gradient: block ranges per class, heaviest class
@@ -857,7 +859,10 @@ __global__ __launch_bounds__(256) void igemm2_group_kernel(const IgemmGroupArgs 
     geo.ood = g.cls[c].ood; geo.ooh = g.cls[c].ooh; geo.oow = g.cls[c].oow; geo.stat_base = g.cls[c].stat_base; geo.ntaps = g.cls[c].ntaps;
     geo.taps = g.cls[c].taps;
     geo.w = g.cls[c].w; geo.bias = g.cls[c].bias; geo.y = g.cls[c].y; geo.statpart = g.cls[c].statpart;
-    igemm2_body<BM, BN, WT, F16, 0>(g.common, geo, (int)blockIdx.x - g.cls[c].blk0, 0);
+    // K-sliced classes: consecutive blocks of a class are the slices of one tile
+    geo.nsplit = g.cls[c].nsplit; geo.slab = g.common.slab + g.cls[c].slab0; geo.cnt = g.common.cnt + g.cls[c].cnt0;
+    const int local = (int)blockIdx.x - g.cls[c].blk0;
+    igemm2_body<BM, BN, WT, F16, 0>(g.common, geo, local / geo.nsplit, local % geo.nsplit);
 }
 
 constexpr int MAX_TABLE_FLOATS = 4 * 2048;        // coefficient table: up to 4 coefficients x 2048 reduction channels
@@ -1045,7 +1050,7 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStr
 
 // ---- grouped launch of residue classes ---------------------------------------------------------------------------------
 bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& pl) {
-    if (n < 2 || n > P3D_IGEMM_CLASSES || pl.splits != 1) return false;
+    if (n < 2 || n > P3D_IGEMM_CLASSES) return false;
     for (int i = 0; i < n; ++i) {
         const IgemmArgs& a = v[i];
         // shared: the gathered operand and every extent / stride; per class: grid, offsets, taps, weights, bias, output, statistics
@@ -1055,7 +1060,7 @@ bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& pl) {
             a.isw != v[0].isw || a.osd != v[0].osd || a.osh != v[0].osh || a.osw != v[0].osw)
             return false;
         const P3dIgemmPlan q = p3d_igemm2_plan(a, 1);
-        if (q.bm != pl.bm || q.bn != pl.bn || q.splits != 1) return false;
+        if (q.bm != pl.bm || q.bn != pl.bn) return false;          // (each class keeps its own K-slice count)
     }
     return true;
 }
@@ -1063,9 +1068,21 @@ bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& pl) {
 namespace {
 template <int BM, int BN>
 hipError_t launch_group_t(IgemmGroupArgs& g, const long long* tiles, hipStream_t s) {
-    long long blocks = 0;
-    for (int q = 0; q < g.nclass; ++q) { g.cls[q].blk0 = (int)blocks; blocks += tiles[q]; }
+    long long blocks = 0, slabs = 0, counters = 0;
+    for (int q = 0; q < g.nclass; ++q) {
+        g.cls[q].blk0 = (int)blocks; blocks += tiles[q] * g.cls[q].nsplit;
+        g.cls[q].slab0 = 0; g.cls[q].cnt0 = 0;
+        if (g.cls[q].nsplit > 1) {
+            g.cls[q].slab0 = slabs * (long long)(BM * BN); g.cls[q].cnt0 = counters;
+            slabs += tiles[q] * g.cls[q].nsplit; counters += tiles[q];
+        }
+    }
     if (blocks <= 0 || blocks >= (1ll << 31)) return blocks <= 0 ? hipSuccess : hipErrorInvalidValue;
+    g.common.slab = nullptr; g.common.cnt = nullptr;
+    if (slabs > 0) {
+        const hipError_t e = p3d_stream_scratch(s, (size_t)slabs * BM * BN, (size_t)counters, &g.common.slab, &g.common.cnt);
+        if (e != hipSuccess) return e;
+    }
     constexpr size_t sm = smem_fixed_bytes<BM, BN, 0>();
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1117,6 +1134,7 @@ hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan
         c.fGd = p3d_fastdiv((unsigned)a.Gd); c.fGh = p3d_fastdiv((unsigned)a.Gh); c.fGw = p3d_fastdiv((unsigned)a.Gw);
         c.ood = a.ood; c.ooh = a.ooh; c.oow = a.oow; c.stat_base = a.stat_base; c.ntaps = a.ntaps;
         c.w = a.w; c.bias = a.bias; c.y = a.y; c.statpart = a.statpart;
+        c.nsplit = std::max(1, p3d_igemm2_plan(a, 1).splits);
         for (int t = 0; t < a.ntaps; ++t) c.taps[t] = a.taps[t];
         tiles[nc] = ((M + pl.bm - 1) / pl.bm) * ((a.Nc + pl.bn - 1) / pl.bn);
         ++nc;

@@ -152,6 +152,8 @@ struct IgemmClass {
     int ntaps;
     int blk0;             // first block of this class in the grouped launch (classes in descending order of work)
     const float* w; const float* bias; float* y; float* statpart;      // per class as well: sibling convs on one input (ST_B)
+    int nsplit;           // K-slices of this class (its blocks: tiles x slices, a tile's slices in consecutive blocks)
+    long long slab0, cnt0;      // this class's share of the launch's slab / counter scratch (floats / counters)
     P3dTap taps[P3D_MAX_TAPS];
 };
 struct IgemmGroupArgs {
@@ -211,7 +213,7 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int allow_split);
 void p3d_tune_begin(hipStream_t s);
 void p3d_tune_end();
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipStream_t s);
-// n launches that differ only in what IgemmClass holds, as ONE launch (no K-slices, no operand transform / gates; n <= 8).
+// n launches that differ only in what IgemmClass holds, as ONE launch (same tile shape, no operand transform / gates; n <= 8).
 // stat_base of every class must be set by the caller (statistics partials of class q start at its stat_base).
 bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& plan);
 hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan& plan, hipStream_t s);
