@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--size", type=int, default=112, help="clip height = width (BASELINE configs[4] uses 32 frames of 224)")
     ap.add_argument("--pointwise", default="fp32", choices=["fp32", "fp16"],
                     help="fp16: 1x1x1 convs on the fp16 MFMA with fp32 accumulate (BASELINE configs[4]); fp16-level parity")
+    ap.add_argument("--attention", default="auto", choices=["auto", "gemm", "flash"],
+                    help="unet++ds: how the attention cores run (p3d_set_attention_mode)")
     ap.add_argument("--bn-fusion", default="default", choices=["default", "off", "fwd", "full"],
                     help="A/B runs: BatchNorm passes of their own / fused into the convs in the forward pass / in both passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,6 +189,8 @@ def main():
                       world_size=world, rank=rank, seed=1)
     if args.pointwise == "fp16":
         sess.set_pointwise_fp16(True)
+    if args.attention != "auto":
+        sess.set_attention_mode(args.attention)
     if args.bn_fusion != "default":
         sess.set_bn_fusion({"off": 0, "fwd": 1, "full": 2}[args.bn_fusion])
     if world > 1 and not rehearsal:
@@ -248,7 +252,7 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "dropout": 0.5},
             "model_tflops": round(value * FLOP_PER_CLIP_FWD_BWD * (T / 16.0) * (S / 112.0) ** 2 / 1e12, 2) if args.structure == "unet" else None,
             "final_loss": loss,
-            "bn_fusion": args.bn_fusion,
+            "bn_fusion": args.bn_fusion, "attention": args.attention,
             "launches_per_step": len(recs),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
             "host_enqueue_ms_one_step_empty_queue": round(1e3 * t_one, 3),

@@ -114,6 +114,15 @@ int p3d_set_pointwise_fp16(p3d_handle* h, int enable);
  * the never-stored activations through the transform); 2: the backward pass is fused as well. */
 int p3d_set_bn_fusion(p3d_handle* h, int enable);
 
+/* The core of attention(), softmax(g f^T) h (utils/network.py:183-185; p3d_unetplusplus_ds, p3d.py:340-397) -- an execution
+ * choice, the arithmetic is the reference's either way (only the order of the sums differs):
+ *   1  three GEMMs per direction around a stored [N_g x N_f] score matrix and attention map (2 x B*N_g*N_f floats per block);
+ *   2  score tiles recomputed on chip, nothing of size N_g x N_f in HBM (blocks of 32, 64, 128 or 256 channels; wider ones
+ *      keep the GEMMs) -- the only way the last block fits at 8 clips of 32x224x224 (B*N_g*N_f = 5e10);
+ *   0  (default) per block: 2 where the score matrix has 2^24 elements or more, else 1.
+ * Switching to 1 allocates the score buffers of blocks that were built without them. */
+int p3d_set_attention_mode(p3d_handle* h, int mode);
+
 /* tf.train.AdamOptimizer(lr, beta1, beta2, epsilon) (train.py:168; defaults 1e-4, .9, .999, 1e-8). */
 int p3d_set_adam(p3d_handle* h, float lr, float beta1, float beta2, float eps);
 

@@ -1800,6 +1800,11 @@ struct p3d_handle {
 
     // ---- self attention, utils/network.py:157-192 (mode 'bn', sub_size 2) --------------------------------------
     struct AttnParams { Param *wf, *bf, *wg, *bg, *wh, *bh, *wo, *bo, *gamma; BN* bn; int ch; std::string name; };
+    // p3d_set_attention_mode: 0 = per site (flash where the score matrix of the site has at least attn_flash_min_scores elements),
+    // 1 = GEMMs around stored scores everywhere, 2 = flash wherever the kernels exist (ch in 32..256)
+    int attn_mode = 0;
+    int64_t attn_flash_min_scores = (int64_t)1 << 24;         // 64 MiB of scores per buffer (measured crossover: DESIGN.md)
+    std::vector<std::function<void()>> attn_gemm_alloc;
     // variables in the reference's creation order: name/conv3d{,_1,_2}, an unnamed top-level conv3d, an unnamed
     // batch_normalization, then the top-level scalar 'gamma'+name (initialised to 0)
     AttnParams attn_declare(const std::string& name, int ch) {
@@ -1835,13 +1840,37 @@ struct p3d_handle {
         const int Ng = gq->D * gq->H * gq->W, Nf = f->D * f->H * f->W, Nfp = (Nf + 3) / 4 * 4;
         const bool pad = Nfp != Nf;
         Act* o = new_act(nm + "/o", B, x->D, x->H, x->W, ch);
-        float* sbuf = dalloc<float>((int64_t)B * Ng * Nfp);       // scores, then the attention map beta (kept for backward)
-        float* dsbuf = dalloc<float>((int64_t)B * Ng * Nfp);      // d beta, then d scores
-        float *fpad = nullptr, *hpad = nullptr, *dfpad = nullptr, *dhpad = nullptr;
-        if (pad) {
-            fpad = dalloc<float>((int64_t)B * Nfp * ci); hpad = dalloc<float>((int64_t)B * Nfp * ch);
-            dfpad = dalloc<float>((int64_t)B * Nfp * ci); dhpad = dalloc<float>((int64_t)B * Nfp * ch);
-        }
+        // Two executions of the core (p3d_set_attention_mode): score tiles recomputed on chip (attention_flash.hip: lse + row
+        // dots are all it keeps), or three GEMMs per direction around a stored score matrix.  The GEMM path's buffers
+        // (2 x B*Ng*Nf floats) are only allocated for sites that may take it.
+        const bool can_flash = p3d_flash_attn_ok(ch);
+        const bool auto_flash = can_flash && (int64_t)B * Ng * Nfp >= attn_flash_min_scores;
+        float* lse = can_flash ? dalloc<float>((int64_t)B * Ng) : nullptr;
+        float* dsum = can_flash ? dalloc<float>((int64_t)B * Ng) : nullptr;
+        struct GemmBufs { float *sbuf = nullptr, *dsbuf = nullptr, *fpad = nullptr, *hpad = nullptr, *dfpad = nullptr, *dhpad = nullptr; };
+        GemmBufs* gb = new GemmBufs();           // lives as long as the handle (ops capture it)
+        auto ensure_gemm = [=]() {
+            if (gb->sbuf) return;
+            gb->sbuf = dalloc<float>((int64_t)B * Ng * Nfp);       // scores, then the attention map beta (kept for backward)
+            gb->dsbuf = dalloc<float>((int64_t)B * Ng * Nfp);      // d beta, then d scores
+            if (pad) {
+                gb->fpad = dalloc<float>((int64_t)B * Nfp * ci); gb->hpad = dalloc<float>((int64_t)B * Nfp * ch);
+                gb->dfpad = dalloc<float>((int64_t)B * Nfp * ci); gb->dhpad = dalloc<float>((int64_t)B * Nfp * ch);
+            }
+        };
+        if (!auto_flash) ensure_gemm();
+        attn_gemm_alloc.push_back(ensure_gemm);
+        bool* ran_flash = new bool(false);       // what the last forward of this site ran (its backward follows)
+        auto flash_args = [=]() {
+            FlashAttnArgs a;
+            memset(&a, 0, sizeof(a));
+            a.B = B; a.Ng = Ng; a.Nf = Nf; a.ch = ch;
+            a.g = gq->p; a.ldg = gq->ld; a.f = f->p; a.ldf = f->ld; a.h = h->p; a.ldh = h->ld;
+            a.o = o->p; a.ldo = o->ld; a.lse = lse;
+            a.d_o = o->g; a.lddo = o->ld; a.dsum = dsum;
+            a.dg = gq->g; a.lddg = gq->ld; a.df = f->g; a.lddf = f->ld; a.dh = h->g; a.lddh = h->ld;
+            return a;
+        };
         char* flg = consume(gq); char* flf = consume(f); char* flh = consume(h);
         {
             Op op;
@@ -1857,7 +1886,16 @@ struct p3d_handle {
                 if (split) zero_strided(c, out, ldo, (int64_t)B * Ng, Nc);
                 for (int b = 0; b < B; ++b) launch_igemm(c, mk(b), split ? 1 : 0);
             };
+            const double pair_flops = 2.0 * B * (double)Ng * Nf * (ci + ch);
+            const double operand_bytes = 4.0 * B * ((double)Ng * (ci + ch) + (double)Nf * (ci + ch));
             op.fwd = [=](const Ctx& c) {
+                *ran_flash = can_flash && (attn_mode == 2 || (attn_mode == 0 && auto_flash));
+                if (*ran_flash) {
+                    launch(c, "flash_fwd_kernel", pair_flops, operand_bytes, [&]() { return p3d_flash_attn_fwd(flash_args(), c.s); });
+                    return;
+                }
+                if (!gb->sbuf) throw P3dError("attention GEMM path without its score buffers (p3d_set_attention_mode allocates them)");
+                float* const sbuf = gb->sbuf; float* const fpad = gb->fpad; float* const hpad = gb->hpad;
                 const float* F = f->p; const float* H = h->p;
                 if (pad) {
                     launch(c, "pad_rows_kernel", 0, 8.0 * B * Nfp * ci, [&]() { return p3d_pad_rows(f->p, fpad, B, Nf, Nfp, ci, c.s); });
@@ -1876,6 +1914,15 @@ struct p3d_handle {
             };
             op.bwd = [=](const Ctx& c) {
                 if (*flg || *flf || *flh) throw P3dError("attention operands have one consumer each");
+                if (*ran_flash) {
+                    if (c.dry) return;
+                    const FlashAttnArgs a = flash_args();
+                    // one entry point, three launches (row dots; dg per query tile; df, dh per key tile)
+                    launch(c, "flash_bwd(rowdot + q + k kernels)", 3.2 * pair_flops, 3 * operand_bytes, [&]() { return p3d_flash_attn_bwd(a, c.s); });
+                    return;
+                }
+                float* const sbuf = gb->sbuf; float* const dsbuf = gb->dsbuf;
+                float* const fpad = gb->fpad; float* const hpad = gb->hpad; float* const dfpad = gb->dfpad; float* const dhpad = gb->dhpad;
                 const float* F = pad ? fpad : f->p; const float* H = pad ? hpad : h->p;
                 float* dF = pad ? dfpad : f->g; float* dH = pad ? dhpad : h->g;
                 gemm_each(c, dsbuf, Nfp, Nfp, [=](int b) {          // d beta = d o * h^T
@@ -2695,6 +2742,17 @@ int p3d_debug_force_plan(int igemm_tile, int igemm_splits, int wgrad_tm, int wgr
     p3d_igemm2_override(igemm_tile, igemm_splits);
     p3d_wgrad2_force_tile(wgrad_tm, wgrad_tn);
     return 0;
+}
+
+int p3d_set_attention_mode(p3d_handle* h, int mode) {
+    API_BEGIN
+    if (!h) throw P3dError("null handle");
+    if (mode < 0 || mode > 2) throw P3dError("attention mode is 0 (per site), 1 (stored scores) or 2 (flash)");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    if (mode == 1) for (auto& f : h->attn_gemm_alloc) f();      // sites that were built flash-only get their score buffers now
+    h->attn_mode = mode;
+    h->drop_step_graph();
+    API_END
 }
 
 int p3d_set_bn_fusion(p3d_handle* h, int enable) {

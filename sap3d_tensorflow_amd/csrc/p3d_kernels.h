@@ -384,6 +384,23 @@ struct AttnMixArgs {                 // z = r * gamma + x  (utils/network.py:191
 };
 hipError_t p3d_attn_mix_fwd(const AttnMixArgs& a, hipStream_t s);
 hipError_t p3d_attn_mix_bwd(const AttnMixArgs& a, hipStream_t s);
+// The attention core  o = softmax(g f^T) h  (utils/network.py:183-185) without the score matrix in HBM (attention_flash.hip):
+// per clip, g [Ng x ch/8] queries, f [Nf x ch/8] keys, h [Nf x ch] values; clip b of a tensor starts b * rows * ld floats in.
+struct FlashAttnArgs {
+    int B, Ng, Nf, ch;                   // ch in {32, 64, 128, 256}; ch/8 channels in g and f
+    const float* g; int ldg;
+    const float* f; int ldf;
+    const float* h; int ldh;
+    float* o; int ldo;                   // forward output [B][Ng][ch]
+    float* lse;                          // [B][Ng]: row maximum + log of the row sum (kept for the backward pass)
+    // backward
+    const float* d_o; int lddo;          // gradient of o
+    float* dsum;                         // [B][Ng] scratch: <d_o, o> per row
+    float* dg; int lddg; float* df; int lddf; float* dh; int lddh;       // written, not accumulated
+};
+bool p3d_flash_attn_ok(int ch);
+hipError_t p3d_flash_attn_fwd(const FlashAttnArgs& a, hipStream_t s);
+hipError_t p3d_flash_attn_bwd(const FlashAttnArgs& a, hipStream_t s);      // three launches: row dots, dg, (df, dh)
 hipError_t p3d_pad_rows(const float* src, float* dst, int B, int N, int Npad, int C, hipStream_t s);     // [B][N][C] -> [B][Npad][C], zero tail
 hipError_t p3d_unpad_rows(const float* src, float* dst, int B, int N, int Npad, int C, hipStream_t s);   // the reverse (tail dropped)
 

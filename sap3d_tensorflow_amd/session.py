@@ -170,6 +170,11 @@ class P3DSession:
         """BatchNorm + ReLU between the convs of a bottleneck on the convs' operand paths (default) or as passes of their own."""
         check(lib().p3d_set_bn_fusion(self._h, int(enable)))      # 0 off, 1 forward, 2 forward + backward
 
+    def set_attention_mode(self, mode="auto"):
+        """How attention() (utils/network.py:183-185) runs: "gemm" stores the score matrix, "flash" recomputes score tiles on
+        chip, "auto" picks per block by the size of the score matrix."""
+        check(lib().p3d_set_attention_mode(self._h, {"auto": 0, "gemm": 1, "flash": 2}[mode]))
+
     def predict_windows(self, x):
         """B windows of gen_pred.py:100-168 at once: row k equals forward(x[k:k+1], training=False) of a batch-1
         session, i.e. every batch-statistics BN normalises each clip by its own statistics."""
