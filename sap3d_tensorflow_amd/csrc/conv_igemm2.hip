@@ -860,9 +860,13 @@ __global__ __launch_bounds__(256) void igemm2_group_kernel(const IgemmGroupArgs 
     geo.taps = g.cls[c].taps;
     geo.w = g.cls[c].w; geo.bias = g.cls[c].bias; geo.y = g.cls[c].y; geo.statpart = g.cls[c].statpart;
     // K-sliced classes: consecutive blocks of a class are the slices of one tile
-    geo.nsplit = g.cls[c].nsplit; geo.slab = g.common.slab + g.cls[c].slab0; geo.cnt = g.common.cnt + g.cls[c].cnt0;
+    // (a tail class starts at tile0 of its grid: the body indexes scratch by tile, so the class's share is rebased by tile0)
+    const int tile0 = g.cls[c].tile0;
+    geo.nsplit = g.cls[c].nsplit;
+    geo.slab = g.common.slab + (g.cls[c].slab0 - (long long)tile0 * geo.nsplit * (BM * BN));
+    geo.cnt = g.common.cnt + (g.cls[c].cnt0 - tile0);
     const int local = (int)blockIdx.x - g.cls[c].blk0;
-    igemm2_body<BM, BN, WT, F16, 0>(g.common, geo, local / geo.nsplit, local % geo.nsplit);
+    igemm2_body<BM, BN, WT, F16, 0>(g.common, geo, tile0 + local / geo.nsplit, local % geo.nsplit);
 }
 
 constexpr int MAX_TABLE_FLOATS = 4 * 2048;        // coefficient table: up to 4 coefficients x 2048 reduction channels
@@ -1043,6 +1047,7 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStr
     for (int q = 0; q < a.ngate; ++q)
         if (!a.gate[q].y || !a.gate[q].out || !a.gate[q].part || (a.gate[q].ldy & 3) || (a.gate[q].ldo & 3)) return hipErrorInvalidValue;
     if (a.ngate && a.statpart) return hipErrorInvalidValue;
+    if (p3d_igemm2_tail_split(a, pl)) return p3d_launch_igemm2_group(&a, 1, pl, s);      // full rounds + a K-sliced tail class
     if (pl.bm == 128 && pl.bn == 128) return launch_t<128, 128>(a, pl, s);
     if (pl.bm == 128 && pl.bn == 64) return launch_t<128, 64>(a, pl, s);
     return launch_t<64, 64>(a, pl, s);
@@ -1104,8 +1109,25 @@ hipError_t launch_group_t(IgemmGroupArgs& g, const long long* tiles, hipStream_t
 }
 }  // namespace
 
+namespace {
+bool tail_split_enabled() {          // P3D_TUNE_NO_TAIL=1 (tuning builds): A/B runs without the K-sliced tail class
+    static const bool on = [] { const char* e = p3d_tune_env("P3D_TUNE_NO_TAIL"); return !(e && atoi(e)); }();
+    return on;
+}
+}  // namespace
+
+// Would the tail of this single launch be cut into K-slices (then it goes out through the grouped kernel)?
+bool p3d_igemm2_tail_split(const IgemmArgs& a, const P3dIgemmPlan& pl) {
+    if (a.at_mode || a.ngate || a.statpart || pl.splits > 1 || !tail_split_enabled()) return false;
+    const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
+    const long long tiles = ((M + pl.bm - 1) / pl.bm) * ((a.Nc + pl.bn - 1) / pl.bn);
+    const long long rem = tiles % 256;
+    const int steps = a.ntaps * ((a.K + BK - 1) / BK);
+    return tiles >= 256 && rem > 0 && std::min<long long>(std::min<long long>(16, 256 / rem), steps / 4) >= 2;
+}
+
 hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan& pl, hipStream_t s) {
-    if (!p3d_igemm2_groupable(v, n, pl)) return hipErrorInvalidValue;
+    if (n == 1 ? !p3d_igemm2_tail_split(v[0], pl) : !p3d_igemm2_groupable(v, n, pl)) return hipErrorInvalidValue;
     // the checks of the single launch, per class
     for (int i = 0; i < n; ++i) {
         const IgemmArgs& a = v[i];
@@ -1138,6 +1160,26 @@ hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan
         for (int t = 0; t < a.ntaps; ++t) c.taps[t] = a.taps[t];
         tiles[nc] = ((M + pl.bm - 1) / pl.bm) * ((a.Nc + pl.bn - 1) / pl.bn);
         ++nc;
+    }
+    // Tail of the last wave: with one block per CU a launch of T tiles takes ceil(T / 256) rounds, and a last round that fills
+    // a small part of the chip costs a whole tile time (deconv3's input gradient at 8 clips: 784 tiles of 128x128 = 3.06
+    // rounds).  The tiles of that round become a class of their own, K-sliced so that its blocks fill the round.
+    if (nc >= 1 && nc < P3D_IGEMM_CLASSES && g.cls[nc - 1].nsplit == 1 && !g.cls[nc - 1].statpart) {
+        long long blocks = 0;
+        for (int q = 0; q < nc; ++q) blocks += tiles[q] * g.cls[q].nsplit;
+        const long long rem = blocks % 256;
+        const IgemmClass& last = g.cls[nc - 1];
+        const int steps = last.ntaps * ((g.common.K + BK - 1) / BK);
+        int sl = rem > 0 ? (int)std::min<long long>(16, 256 / rem) : 1;
+        sl = std::min(sl, steps / 4);
+        if (blocks >= 256 && rem > 0 && rem < tiles[nc - 1] && sl >= 2 && tail_split_enabled()) {
+            g.cls[nc] = last;
+            g.cls[nc].tile0 = (int)(tiles[nc - 1] - rem);
+            g.cls[nc].nsplit = sl;
+            tiles[nc] = rem;
+            tiles[nc - 1] -= rem;
+            ++nc;
+        }
     }
     g.nclass = nc;
     if (nc == 0) return hipSuccess;

@@ -153,6 +153,7 @@ struct IgemmClass {
     int blk0;             // first block of this class in the grouped launch (classes in descending order of work)
     const float* w; const float* bias; float* y; float* statpart;      // per class as well: sibling convs on one input (ST_B)
     int nsplit;           // K-slices of this class (its blocks: tiles x slices, a tile's slices in consecutive blocks)
+    int tile0;            // first output tile of this class in its grid (> 0: the K-sliced tail of the class before it)
     long long slab0, cnt0;      // this class's share of the launch's slab / counter scratch (floats / counters)
     P3dTap taps[P3D_MAX_TAPS];
 };
@@ -215,6 +216,7 @@ void p3d_tune_end();
 hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipStream_t s);
 // n launches that differ only in what IgemmClass holds, as ONE launch (same tile shape, no operand transform / gates; n <= 8).
 // stat_base of every class must be set by the caller (statistics partials of class q start at its stat_base).
+bool p3d_igemm2_tail_split(const IgemmArgs& a, const P3dIgemmPlan& pl);      // a single launch whose last round gets K-sliced (goes out grouped)
 bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& plan);
 hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan& plan, hipStream_t s);
 void p3d_igemm2_override(int tile, int splits);   // test / tools hook: force the tile (0: 64x64, 1: 128x64, 2: 128x128) and the K-slice count; -1 / 0 = no override

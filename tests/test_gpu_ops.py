@@ -146,6 +146,32 @@ def test_filter_gradient_tile_shapes(tile, xs, k, co):
         lib().p3d_debug_force_plan(-1, 0, 0, 0)
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_conv_last_round_is_k_sliced(tile):
+    """A launch whose tile count is a little over a multiple of the 256 CUs: the tiles of the last round go out as a K-sliced
+    class of the same launch (conv_igemm2.hip, p3d_igemm2_tail_split).  33792 output rows = 528 / 264 / 264 tiles of
+    64x64 / 128x64 / 128x128; forward and input gradient against the oracle."""
+    from sap3d_tensorflow_amd import lib, ops
+    xs, k, co, s = (1, 8, 66, 64, 32), (3, 3, 3), 128, (1, 1, 1)
+    rng = np.random.default_rng(17)
+    x = rnd(rng, xs)
+    w = rnd(rng, k + (xs[4], co)) * 0.1
+    b = rnd(rng, (co,))
+    want = nn.conv3d_forward(x.astype(np.float64), w.astype(np.float64), s) + b
+    dy = rnd(rng, want.shape)
+    want_dx = nn.conv3d_backward_input(dy.astype(np.float64), w.astype(np.float64), s, xs)
+    lib().p3d_debug_force_plan(tile, 0, 0, 0)
+    try:
+        got = ops.conv3d(x, w, s, bias=b)
+        got_dx = ops.conv3d_backprop_input(xs, w, dy, s)
+        again = ops.conv3d(x, w, s, bias=b)
+    finally:
+        lib().p3d_debug_force_plan(-1, 0, 0, 0)
+    close(got, want)
+    close(got_dx, want_dx)
+    assert np.array_equal(got, again)
+
+
 def _filter_gradient_case(ops, xs, k, co):
     rng = np.random.default_rng(5)
     x = rnd(rng, xs)
