@@ -837,6 +837,15 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
     }
 }
 
+// Block -> tile so that the blocks of one XCD (block index mod 8) work on CONSECUTIVE tiles: the N tiles of one row range and
+// the row ranges next to it (the neighbours a k x k x k tap reaches into) then share that XCD's L2 instead of being
+// fetched by eight of them.  A bijection on [0, T); launches with few tiles keep the identity.
+__device__ __forceinline__ int xcd_tile(int b, int T, int min_tiles) {
+    if (T < min_tiles) return b;
+    const int x = b & 7, q = T >> 3, r = T & 7;
+    return x * q + min(x, r) + (b >> 3);
+}
+
 template <int BM, int BN, bool WT, bool F16 = false, int AT = 0>
 __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     Geo geo;
@@ -844,7 +853,8 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
     geo.ood = p.ood; geo.ooh = p.ooh; geo.oow = p.oow; geo.stat_base = p.stat_base; geo.ntaps = p.ntaps; geo.taps = p.taps;
     geo.w = p.w; geo.bias = p.bias; geo.y = p.y; geo.statpart = p.statpart;
     geo.nsplit = p.nsplit; geo.slab = p.slab; geo.cnt = p.cnt;
-    igemm2_body<BM, BN, WT, F16, AT>(p, geo, (int)blockIdx.x, (int)blockIdx.y);      // block -> (output tile, K-slice)
+    const int tile = p.nsplit == 1 ? xcd_tile((int)blockIdx.x, (int)gridDim.x, p.xcd_min_tiles) : (int)blockIdx.x;
+    igemm2_body<BM, BN, WT, F16, AT>(p, geo, tile, (int)blockIdx.y);      // block -> (output tile, K-slice)
 }
 // One launch for the residue classes of a transposed conv / strided input gradient: block ranges per class, heaviest class
 // first (a class with eight taps runs eight times as long per tile as one with a single tap: the late blocks are the short ones)
@@ -866,7 +876,8 @@ __global__ __launch_bounds__(256) void igemm2_group_kernel(const IgemmGroupArgs 
     geo.slab = g.common.slab + (g.cls[c].slab0 - (long long)tile0 * geo.nsplit * (BM * BN));
     geo.cnt = g.common.cnt + (g.cls[c].cnt0 - tile0);
     const int local = (int)blockIdx.x - g.cls[c].blk0;
-    igemm2_body<BM, BN, WT, F16, 0>(g.common, geo, tile0 + local / geo.nsplit, local % geo.nsplit);
+    const int tile = geo.nsplit == 1 ? xcd_tile(local, g.cls[c].ntiles, g.common.xcd_min_tiles) : local / geo.nsplit;
+    igemm2_body<BM, BN, WT, F16, 0>(g.common, geo, tile0 + tile, local % geo.nsplit);
 }
 
 constexpr int MAX_TABLE_FLOATS = 4 * 2048;        // coefficient table: up to 4 coefficients x 2048 reduction channels
@@ -888,6 +899,15 @@ hipError_t launch_variant(const IgemmArgs& a, dim3 grid, hipStream_t s) {
     return hipGetLastError();
 }
 
+int xcd_min_tiles() {                // P3D_TUNE_XCD_MIN_TILES (tuning builds): A/B runs of the XCD-contiguous tile order
+    static const int v = [] { const char* e = p3d_tune_env("P3D_TUNE_XCD_MIN_TILES"); return e ? atoi(e) : 64; }();
+    return v;
+}
+bool tail_split_enabled() {          // P3D_TUNE_NO_TAIL=1 (tuning builds): A/B runs without the K-sliced tail class
+    static const bool on = [] { const char* e = p3d_tune_env("P3D_TUNE_NO_TAIL"); return !(e && atoi(e)); }();
+    return on;
+}
+
 template <int BM, int BN>
 hipError_t launch_t(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) {
     IgemmArgs a = a0;
@@ -895,6 +915,7 @@ hipError_t launch_t(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) 
     const long long tiles = ((M + BM - 1) / BM) * ((a.Nc + BN - 1) / BN);
     const int splits = pl.splits < 1 ? 1 : pl.splits;
     a.nsplit = splits;
+    a.xcd_min_tiles = xcd_min_tiles();
     a.slab = nullptr; a.cnt = nullptr;
     if (splits > 1) {
         const hipError_t e = p3d_stream_scratch(s, (size_t)tiles * splits * BM * BN, (size_t)tiles, &a.slab, &a.cnt);
@@ -1076,6 +1097,7 @@ hipError_t launch_group_t(IgemmGroupArgs& g, const long long* tiles, hipStream_t
     long long blocks = 0, slabs = 0, counters = 0;
     for (int q = 0; q < g.nclass; ++q) {
         g.cls[q].blk0 = (int)blocks; blocks += tiles[q] * g.cls[q].nsplit;
+        g.cls[q].ntiles = (int)tiles[q];
         g.cls[q].slab0 = 0; g.cls[q].cnt0 = 0;
         if (g.cls[q].nsplit > 1) {
             g.cls[q].slab0 = slabs * (long long)(BM * BN); g.cls[q].cnt0 = counters;
@@ -1109,12 +1131,6 @@ hipError_t launch_group_t(IgemmGroupArgs& g, const long long* tiles, hipStream_t
 }
 }  // namespace
 
-namespace {
-bool tail_split_enabled() {          // P3D_TUNE_NO_TAIL=1 (tuning builds): A/B runs without the K-sliced tail class
-    static const bool on = [] { const char* e = p3d_tune_env("P3D_TUNE_NO_TAIL"); return !(e && atoi(e)); }();
-    return on;
-}
-}  // namespace
 
 // Would the tail of this single launch be cut into K-slices (then it goes out through the grouped kernel)?
 bool p3d_igemm2_tail_split(const IgemmArgs& a, const P3dIgemmPlan& pl) {
@@ -1144,6 +1160,7 @@ hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan
     IgemmGroupArgs g;
     memset(&g, 0, sizeof(g));
     g.common = v[0];
+    g.common.xcd_min_tiles = xcd_min_tiles();
     g.common.nsplit = 1; g.common.slab = nullptr; g.common.cnt = nullptr;
     long long tiles[P3D_IGEMM_CLASSES];
     int nc = 0;

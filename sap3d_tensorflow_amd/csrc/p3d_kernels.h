@@ -127,6 +127,7 @@ struct IgemmArgs {
     // (bit-reproducible, unlike atomics), applies bias / accumulate / statistics and writes the output.
     float* slab; unsigned* cnt; int nsplit;
     int f16;              // 1: round the operand fragments to fp16 and use the fp16 MFMA (fp32 accumulate); pointwise convs of configs[4]
+    int xcd_min_tiles;    // set by the launcher: launches / classes with at least this many tiles map consecutive tiles to one XCD
     // fused BatchNorm on the A operand (P3D_AT_*): x2 is the second source on the gathered lattice (RELU2, GRAD)
     int at_mode;
     const float* x2; int ldx2;
@@ -154,6 +155,7 @@ struct IgemmClass {
     const float* w; const float* bias; float* y; float* statpart;      // per class as well: sibling convs on one input (ST_B)
     int nsplit;           // K-slices of this class (its blocks: tiles x slices, a tile's slices in consecutive blocks)
     int tile0;            // first output tile of this class in its grid (> 0: the K-sliced tail of the class before it)
+    int ntiles;           // output tiles of this class
     long long slab0, cnt0;      // this class's share of the launch's slab / counter scratch (floats / counters)
     P3dTap taps[P3D_MAX_TAPS];
 };
