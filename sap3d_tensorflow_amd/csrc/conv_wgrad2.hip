@@ -373,10 +373,17 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
 
     const long long M = (long long)p.N * p.Gd * p.Gh * p.Gw;
     const int KT = p.pair ? 1 : (p.K + BM - 1) / BM, NT = (p.Nc + BN - 1) / BN;
-    // consecutive blocks are the cuts of one tile: with 8 cuts, cut c of every tile shares XCD c's L2 (speed only)
+    // Block order (speed only): the blocks of one XCD (block index mod 8) take CONSECUTIVE (cut, tile) pairs, cut-major, so
+    // the taps and channel tiles that walk the same position range -- the same x and dy rows -- share that XCD's L2.
     const int local = (int)blockIdx.x - p.blk0;
-    const int tile_local = local / p.ksplit;
-    const int cut = local - tile_local * p.ksplit;
+    const int ntiles = (p.pair ? (p.ntaps + 1) / 2 : p.ntaps) * KT * NT;
+    int v = local;
+    {
+        const int T = ntiles * p.ksplit;
+        if (T >= 64) { const int x = local & 7, q = T >> 3, r = T & 7; v = x * q + min(x, r) + (local >> 3); }
+    }
+    const int cut = v / ntiles;
+    const int tile_local = v - cut * ntiles;
     int b = tile_local;
     const int nt = b % NT; b /= NT;
     const int kt = b % KT;
