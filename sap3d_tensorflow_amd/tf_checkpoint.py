@@ -13,7 +13,8 @@ by TensorFlow was available; the format is restated from TensorFlow's published 
 tensorflow/core/protobuf/tensor_bundle.proto (BundleHeaderProto, BundleEntryProto), tensorflow/core/lib/io/format.h +
 table_builder.cc (the LevelDB-style table of `<prefix>.index`: prefix-compressed blocks with restart arrays, 5-byte
 block trailers, 48-byte footer with magic 0xdb4775248b80fb57) and tensorflow/core/lib/hash/crc32c.h (masked CRC-32C).
-What pins it here: CRC-32C known answers, wire-format checks and write -> read round trips (tests/test_tf_checkpoint.py).
+What pins it here: CRC-32C known answers, wire-format checks, a two-variable `.index` file assembled by hand from those
+definitions and compared byte for byte, and write -> read round trips (tests/test_tf_checkpoint.py).
 
 A bundle is `<prefix>.index` (the table: key "" -> header, tensor name -> entry {dtype, shape, shard, offset, size,
 crc32c}) plus `<prefix>.data-0000N-of-0000M` (raw little-endian tensor bytes).  Only what tf.train.Saver writes for
@@ -294,6 +295,27 @@ def _block(entries, restart_interval=16):
     return bytes(out)
 
 
+def _short_successor(key):
+    """table_builder.cc Finish(): the index key of the LAST data block is the shortest key >= the block's last key --
+    its first byte that is not 0xff incremented, the rest dropped (BytewiseComparator::FindShortSuccessor)."""
+    for i, b in enumerate(key):
+        if b != 0xFF:
+            return key[:i] + bytes([b + 1])
+    return key
+
+
+def _shortest_separator(start, limit):
+    """table_builder.cc Add(): the index key of a data block followed by another one is the shortest key in
+    [last key of the block, first key of the next) (BytewiseComparator::FindShortestSeparator)."""
+    m = min(len(start), len(limit))
+    d = 0
+    while d < m and start[d] == limit[d]:
+        d += 1
+    if d < m and start[d] < 0xFF and start[d] + 1 < limit[d]:
+        return start[:d] + bytes([start[d] + 1])
+    return start
+
+
 def _with_trailer(block):
     # 1 byte compression type (0 = none) + masked crc32c over block + type byte
     crc = mask_crc(crc32c(block + b"\x00"))
@@ -428,9 +450,12 @@ def read_checkpoint(prefix, verify=True, names=None):
     return out
 
 
-def write_checkpoint(prefix, variables, block_bytes=4096):
+def write_checkpoint(prefix, variables, block_bytes=262144):
     """Write {name: array} as `<prefix>.index` + `<prefix>.data-00000-of-00001`, the layout tf.train.Saver(write_version=V2)
-    produces for unpartitioned variables (entries sorted by name, tensors back to back in that order)."""
+    produces for unpartitioned variables (entries sorted by name, tensors back to back in that order).  The table follows
+    table_builder.cc step by step: a data block is closed once its size estimate (entries + restart array + count) reaches
+    table::Options::block_size (262144 in TensorFlow), its index key is the shortest separator to the next block's first
+    key (the short successor of its last key for the final block), restart intervals 16 / 1, no compression."""
     names = sorted(variables)
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
     entries = [(b"", _header_proto(1))]
@@ -447,23 +472,27 @@ def write_checkpoint(prefix, variables, block_bytes=4096):
     # data blocks of ~block_bytes, then metaindex (empty), index, footer
     out = bytearray()
     index = []
-    cur, cur_bytes = [], 0
+    cur = []
+    pending = None                      # (last key, handle) of a closed block whose index entry waits for the next key
 
     def flush():
-        nonlocal cur, cur_bytes
-        if not cur:
-            return
+        nonlocal cur, pending
         blk = _block(cur)
-        index.append((cur[-1][0], _varint(len(out)) + _varint(len(blk))))
+        pending = (cur[-1][0], _varint(len(out)) + _varint(len(blk)))
         out.extend(_with_trailer(blk))
-        cur, cur_bytes = [], 0
+        cur = []
 
     for k, v in entries:
+        if pending:
+            index.append((_shortest_separator(pending[0], k), pending[1]))
+            pending = None
         cur.append((k, v))
-        cur_bytes += len(k) + len(v) + 3
-        if cur_bytes >= block_bytes:
+        if len(_block(cur)) >= block_bytes:        # BlockBuilder::CurrentSizeEstimate() is exact for an uncompressed block
             flush()
-    flush()
+    if cur:
+        flush()
+    if pending:
+        index.append((_short_successor(pending[0]), pending[1]))
     meta = _block([])
     meta_handle = _varint(len(out)) + _varint(len(meta))
     out.extend(_with_trailer(meta))

@@ -104,3 +104,24 @@ def test_no_floating_point_atomics_in_the_kernel_sources():
             if re.search(r"unsafeAtomicAdd|atomicAdd\s*\(\s*(?!&cnt\[)|atomic_add_f|__hip_atomic_fetch_add\s*\([^,]*,\s*[^,]*[.f]", code):
                 bad.append("%s:%d: %s" % (os.path.basename(f), i, line.strip()))
     assert not bad, bad
+
+
+def test_product_build_reads_only_its_documented_environment():
+    """The shipped library reads four environment variables ("Execution switches"); every tuning switch goes
+    through p3d_tune_env, which a build without -DP3D_TUNING compiles to "not set" -- a stray P3D_TUNE_* variable in a
+    training job cannot change results."""
+    import glob
+    import re
+    direct, names = [], set()
+    for f in sorted(glob.glob(os.path.join(ROOT, "sap3d_tensorflow_amd", "csrc", "*"))):
+        for i, line in enumerate(open(f, errors="replace"), 1):
+            code = line.split("//")[0]
+            for m in re.finditer(r"(?<![_a-zA-Z])getenv\s*\(\s*(\"[A-Z0-9_]+\"|name)", code):
+                direct.append("%s:%d" % (os.path.basename(f), i))
+                if m.group(1) != "name":
+                    names.add(m.group(1).strip('"'))
+    assert len(direct) <= 6, direct
+    assert names == {"P3D_DEBUG_SYNC", "P3D_GRAPH", "P3D_NO_SIDE_STREAM", "P3D_BUCKET_MB"}, names
+    hdr = open(os.path.join(ROOT, "sap3d_tensorflow_amd", "csrc", "p3d_kernels.h")).read()
+    body = hdr[hdr.index("p3d_tune_env"):]
+    assert re.search(r"#if defined\(P3D_TUNING\)\s+return getenv\(name\);\s+#else", body), "p3d_tune_env must be compiled out of the product build"

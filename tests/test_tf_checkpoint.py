@@ -53,7 +53,7 @@ def test_round_trip_and_state_file(tmp_path):
     rng = np.random.default_rng(1)
     m = _model(rng)
     prefix = str(tmp_path / "model" / "run" / "p3d_1000.ckpt")
-    tfc.write_checkpoint(prefix, m)
+    tfc.write_checkpoint(prefix, m, block_bytes=4096)      # several data blocks: separator keys in the index block
     assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")
     raw = open(prefix + ".index", "rb").read()
     assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57
@@ -154,3 +154,74 @@ def test_dropped_checkpoints_lose_every_file_of_their_prefix(tmp_path):
     left = sorted(os.listdir(d))
     assert not [f for f in left if f.startswith("p3d_1.ckpt")], left
     assert [f for f in left if f.startswith("p3d_2.ckpt")] and [f for f in left if f.startswith("p3d_3.ckpt")]
+
+
+def _crc32c_bitwise(data):
+    """CRC-32C straight from its definition (reflected polynomial 0x82F63B78, one bit at a time): shares nothing with the
+    table-driven code under test."""
+    crc = 0xFFFFFFFF
+    for b in data:
+        crc ^= b
+        for _ in range(8):
+            crc = (crc >> 1) ^ (0x82F63B78 if crc & 1 else 0)
+    return crc ^ 0xFFFFFFFF
+
+
+def _masked(data):
+    c = _crc32c_bitwise(data)
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_index_file_is_byte_for_byte_what_the_format_prescribes(tmp_path):
+    """A two-variable bundle assembled BY HAND from the published format (tensor_bundle.proto, table_builder.cc, format.cc,
+    crc32c.h) -- not from a TensorFlow-written file, none exists here -- against what write_checkpoint emits.  Guards the
+    writer against a bug that its own reader would mirror."""
+    import struct
+    a = np.array([1.0, 2.0], np.float32)
+    c = np.int32(7).reshape(())
+    prefix = str(tmp_path / "g.ckpt")
+    tfc.write_checkpoint(prefix, {"a": a, "b/c": c})
+    a_raw = struct.pack("<2f", 1.0, 2.0)
+    c_raw = struct.pack("<i", 7)
+    assert open(prefix + ".data-00000-of-00001", "rb").read() == a_raw + c_raw
+    # values: BundleHeaderProto{num_shards: 1, version{producer: 1}}; BundleEntryProto per tensor (zero-valued fields omitted)
+    header = bytes([0x08, 0x01, 0x1A, 0x02, 0x08, 0x01])
+    ent_a = bytes([0x08, 0x01,                            # dtype DT_FLOAT
+                   0x12, 0x04, 0x12, 0x02, 0x08, 0x02,     # shape { dim { size: 2 } }
+                   0x28, 0x08,                             # size 8 (offset 0 omitted)
+                   0x35]) + struct.pack("<I", _masked(a_raw))
+    ent_c = bytes([0x08, 0x03,                            # dtype DT_INT32
+                   0x12, 0x00,                             # shape {} (rank 0)
+                   0x20, 0x08,                             # offset 8
+                   0x28, 0x04,                             # size 4
+                   0x35]) + struct.pack("<I", _masked(c_raw))
+    # data block: entries (shared, non-shared, value length, key suffix, value), one restart at 0, restart count
+    data = bytes([0, 0, len(header)]) + header
+    data += bytes([0, 1, len(ent_a)]) + b"a" + ent_a
+    data += bytes([0, 3, len(ent_c)]) + b"b/c" + ent_c
+    data += struct.pack("<II", 0, 1)
+    trailer = lambda blk: blk + b"\x00" + struct.pack("<I", _masked(blk + b"\x00"))      # type 0 = uncompressed, masked CRC
+    out = trailer(data)
+    meta = struct.pack("<II", 0, 1)                          # empty metaindex block
+    meta_off = len(out)
+    out += trailer(meta)
+    # index block: last data block -> key FindShortSuccessor("b/c") = "c", value = BlockHandle(offset 0, size)
+    assert len(data) < 128 and meta_off < 128                # one-byte varints below
+    handle = bytes([0, len(data)])
+    index = bytes([0, 1, len(handle)]) + b"c" + handle + struct.pack("<II", 0, 1)
+    index_off = len(out)
+    out += trailer(index)
+    footer = bytes([meta_off, len(meta), index_off, len(index)])
+    footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57)
+    out += footer
+    assert open(prefix + ".index", "rb").read() == out
+    got = tfc.read_checkpoint(prefix)
+    assert np.array_equal(got["a"], a) and got["b/c"].shape == () and int(got["b/c"]) == 7
+
+
+def test_index_keys_are_shortest_separators():
+    assert tfc._short_successor(b"b/c") == b"c"
+    assert tfc._short_successor(b"\xff\xffa") == b"\xff\xffb"
+    assert tfc._shortest_separator(b"block12/w", b"block2/w") == b"block12/w"      # '1' + 1 == '2': no room
+    assert tfc._shortest_separator(b"abcdef", b"abzz") == b"abd"
+    assert tfc._shortest_separator(b"ab", b"abc") == b"ab"                          # a prefix of the limit stays
