@@ -199,6 +199,12 @@ int p3d_op_max_pool3d_grad(int device, const float* x, const int64_t xshape[5], 
 /* BiasAddGrad of tf.nn.bias_add (the bias of tf.layers.conv3d / conv3d_transpose, p3d.py:147-150): dbias[c] = sum over
  * rows of dy[row][c]; fixed summation order, bit-identical run to run. */
 int p3d_op_bias_add_grad(int device, const float* dy, int64_t rows, int channels, float* dbias);
+/* The core of attention(), utils/network.py:183-185, on flattened operands:
+ *     s = tf.matmul(hw_flatten(g), hw_flatten(f), transpose_b=True); beta = tf.nn.softmax(s); o = tf.matmul(beta, hw_flatten(h))
+ * g [batch][n_g][ch/8], f [batch][n_f][ch/8], h [batch][n_f][ch] -> o [batch][n_g][ch], on the kernels that keep the score
+ * matrix on chip (ch in {32, 64, 128, 256}).  With d_o (the gradient of o) it also writes dg, df, dh. */
+int p3d_op_attention_core(int device, int batch, int n_g, int n_f, int ch, const float* g, const float* f, const float* h,
+                          float* o, const float* d_o, float* dg, float* df, float* dh);
 
 /* ---- validation metrics and frame pre-processing: the steps either side of the path.
  *      Host arrays in and out, float64 results.  Maps are float32 [n_maps][n_pix] of ONE shape (the reference's

@@ -72,6 +72,7 @@ SIGNATURES = {
     "p3d_op_max_pool3d": (C.c_int, [C.c_int, _fp, _i64p, _ip, _ip, _fp]),
     "p3d_op_max_pool3d_grad": (C.c_int, [C.c_int, _fp, _i64p, _ip, _ip, _fp, _fp]),
     "p3d_op_bias_add_grad": (C.c_int, [C.c_int, _fp, C.c_int64, C.c_int, _fp]),
+    "p3d_op_attention_core": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "p3d_metric_cc": (C.c_int, [C.c_int, _fp, _fp, C.c_int, C.c_int, _dp]),
     "p3d_metric_sim": (C.c_int, [C.c_int, _fp, _fp, C.c_int, C.c_int, _dp]),
     "p3d_metric_nss": (C.c_int, [C.c_int, _fp, _fp, C.c_int, C.c_int, _dp]),

@@ -3157,6 +3157,33 @@ int p3d_op_bias_add_grad(int device, const float* dyh, int64_t rows, int channel
     API_END
 }
 
+int p3d_op_attention_core(int device, int batch, int n_g, int n_f, int ch, const float* gh, const float* fh, const float* hh,
+                          float* o, const float* d_o, float* dg, float* df, float* dh) {
+    API_BEGIN
+    if (!gh || !fh || !hh || !o) throw P3dError("null argument");
+    if (!p3d_flash_attn_ok(ch)) throw P3dError("attention_core: ch must be 32, 64, 128 or 256");
+    if (batch < 1 || n_g < 1 || n_f < 1) throw P3dError("attention_core needs at least one clip, query and key");
+    if (d_o && (!dg || !df || !dh)) throw P3dError("attention_core: the backward pass writes dg, df and dh");
+    HIPCHECK(hipSetDevice(device));
+    const int ci = ch / 8;
+    const int64_t ng = (int64_t)batch * n_g, nf = (int64_t)batch * n_f;
+    DevBuf g(ng * ci, gh), f(nf * ci, fh), h(nf * ch, hh), out(ng * ch), lse(ng), dsum(ng);
+    FlashAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = batch; a.Ng = n_g; a.Nf = n_f; a.ch = ch;
+    a.g = g.p; a.ldg = ci; a.f = f.p; a.ldf = ci; a.h = h.p; a.ldh = ch; a.o = out.p; a.ldo = ch; a.lse = lse.p;
+    HIPCHECK(p3d_flash_attn_fwd(a, nullptr));
+    out.get(o, ng * ch);
+    if (d_o) {
+        DevBuf dout(ng * ch, d_o), gg(ng * ci), gf(nf * ci), gv(nf * ch);
+        a.d_o = dout.p; a.lddo = ch; a.dsum = dsum.p;
+        a.dg = gg.p; a.lddg = ci; a.df = gf.p; a.lddf = ci; a.dh = gv.p; a.lddh = ch;
+        HIPCHECK(p3d_flash_attn_bwd(a, nullptr));
+        gg.get(dg, ng * ci); gf.get(df, nf * ci); gv.get(dh, nf * ch);
+    }
+    API_END
+}
+
 }  // extern "C"
 
 // ---- metrics / pre-processing entry points (metrics.hip) -------------------------------------------------------

@@ -85,6 +85,26 @@ def bias_add_grad(dy, device=0):
     return out
 
 
+def attention_core(g, f, h, d_o=None, device=0):
+    """utils/network.py:183-185 on flattened operands: o = softmax(g f^T) h for g [B, Ng, ch/8], f [B, Nf, ch/8], h [B, Nf, ch]
+    (ch in 32, 64, 128, 256), the score matrix never stored.  With d_o (gradient of o): returns (o, dg, df, dh)."""
+    g, f, h = _f32(g), _f32(f), _f32(h)
+    B, ng, ci = g.shape
+    nf, ch = h.shape[1], h.shape[2]
+    if f.shape != (B, nf, ci) or h.shape[0] != B or ci * 8 != ch:
+        raise ValueError("attention_core: g [B,Ng,ch/8], f [B,Nf,ch/8], h [B,Nf,ch]")
+    o = np.empty((B, ng, ch), np.float32)
+    if d_o is None:
+        check(lib().p3d_op_attention_core(device, B, ng, nf, ch, fptr(g), fptr(f), fptr(h), fptr(o), None, None, None, None))
+        return o
+    d = _f32(d_o)
+    if d.shape != o.shape:
+        raise ValueError("attention_core: d_o has the shape of o")
+    dg, df, dh = np.empty_like(g), np.empty_like(f), np.empty_like(h)
+    check(lib().p3d_op_attention_core(device, B, ng, nf, ch, fptr(g), fptr(f), fptr(h), fptr(o), fptr(d), fptr(dg), fptr(df), fptr(dh)))
+    return o, dg, df, dh
+
+
 def max_pool3d(x, ksize, strides, padding="SAME", device=0):
     """tf.nn.max_pool3d(x, [1,kd,kh,kw,1], [1,sd,sh,sw,1], 'SAME')."""
     x = _f32(x)

@@ -183,3 +183,43 @@ def _filter_gradient_case(ops, xs, k, co):
     close(got_db, dy.astype(np.float64).reshape(-1, co).sum(0))
     again, _ = ops.conv3d_backprop_filter(x, k + (xs[4], co), dy, s, with_bias=True)
     assert np.array_equal(got_dw, again)
+
+
+ATTN_CASES = [
+    (2, 300, 77, 32),        # ragged query and key tiles
+    (1, 129, 33, 64),        # one row past a tile on both sides
+    (2, 128, 64, 128),       # exact tiles
+    (1, 50, 200, 256),       # widest instantiation, more keys than queries
+    (3, 5, 3, 32),           # smaller than any tile
+]
+
+
+@pytest.mark.parametrize("B,ng,nf,ch", ATTN_CASES)
+def test_attention_core_forward_and_grads(B, ng, nf, ch):
+    """softmax(g f^T) h (utils/network.py:183-185) on the kernels that keep the scores on chip, against float64 numpy:
+    forward, and dg / df / dh for a random gradient of o.  Scores of a few units, so the softmax is neither flat nor one-hot."""
+    from sap3d_tensorflow_amd import ops
+    rng = np.random.default_rng(ch * 1000 + ng)
+    ci = ch // 8
+    g = rnd(rng, (B, ng, ci)) * (2.0 / np.sqrt(ci)) ** 0.5
+    f = rnd(rng, (B, nf, ci)) * (2.0 / np.sqrt(ci)) ** 0.5 * 2
+    h = rnd(rng, (B, nf, ch))
+    d_o = rnd(rng, (B, ng, ch))
+    g64, f64, h64, d64 = (a.astype(np.float64) for a in (g, f, h, d_o))
+    s = g64 @ f64.transpose(0, 2, 1)
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    want = p @ h64
+    dp = d64 @ h64.transpose(0, 2, 1)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True))
+    want_dg, want_df, want_dh = ds @ f64, ds.transpose(0, 2, 1) @ g64, p.transpose(0, 2, 1) @ d64
+    assert 0.02 < p.max(-1).mean() < 0.9
+    got = ops.attention_core(g, f, h)
+    close(got, want)
+    o, dg, df, dh = ops.attention_core(g, f, h, d_o)
+    assert np.array_equal(o, got)
+    close(dh, want_dh)
+    close(dg, want_dg, 1e-4)         # ds = p (dp - <p, dp>) cancels: an fp32 rounding of dp is 1e-7 of |dp|, not of the difference
+    close(df, want_df, 1e-4)
+    again = ops.attention_core(g, f, h, d_o)
+    assert all(np.array_equal(a, b) for a, b in zip((o, dg, df, dh), again))
