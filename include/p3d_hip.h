@@ -177,6 +177,10 @@ int p3d_comm_init(p3d_handle* h, const void* id);
 int p3d_debug_bucket_audit(p3d_handle* h, float dropout_rate, uint64_t seed, int64_t bucket_floats, int64_t* lo, int64_t* hi,
                            int32_t* after_op, int cap, int64_t* n_train, int64_t* stale);
 
+/* Test hook: synchronises the device and returns how many arrival counters of the K-slice exchange scratch are non-zero
+ * (every sliced launch re-zeroes its own: anything but 0 means a launch left the scratch dirty); -1 on a HIP error. */
+int64_t p3d_debug_dirty_counters(void);
+
 /* Test hook (process-wide): force the tile / K-slice plan of the convolution kernels where a problem allows it, so that
  * every instantiation is reachable from the op-level parity tests.  igemm_tile: 0 = 64x64, 1 = 128x64, 2 = 128x128,
  * -1 = the plan's choice; igemm_splits: K-slices, 0 = the plan's; wgrad_tm / wgrad_tn: 64 or 128, 0 = the plan's. */

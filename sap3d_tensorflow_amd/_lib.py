@@ -49,6 +49,7 @@ SIGNATURES = {
     "p3d_set_pointwise_fp16": (C.c_int, [C.c_void_p, C.c_int]),
     "p3d_set_bn_fusion": (C.c_int, [C.c_void_p, C.c_int]),
     "p3d_set_attention_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "p3d_debug_dirty_counters": (C.c_int64, []),
     "p3d_debug_force_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "p3d_train_step": (C.c_int, [C.c_void_p, _fp, _fp, C.c_float, C.c_uint64, _fp]),
     "p3d_backward": (C.c_int, [C.c_void_p, _fp, _fp, C.c_float, C.c_uint64, _fp, _fp]),

@@ -907,6 +907,22 @@ bool tail_split_enabled() {          // P3D_TUNE_NO_TAIL=1 (tuning builds): A/B 
     static const bool on = [] { const char* e = p3d_tune_env("P3D_TUNE_NO_TAIL"); return !(e && atoi(e)); }();
     return on;
 }
+// K-slices for the `rem` tiles of a launch's last round (1: leave them whole).  Whole, they cost one tile time whatever
+// their number; cut into s slices they run in ceil(rem * s / 256) rounds of 1/s tile time each, plus the slab exchange
+// (3 + 0.4 s us, the fit of heuristic_plan).  136 tiles of 144 steps (deconv2's input gradient): s = 7 -> 4 rounds of 1/7.
+int tail_slices(long long rem, int steps, int bm, int bn) {
+    if (rem <= 0 || !tail_split_enabled()) return 1;
+    const double step_us = bm * bn == 16384 ? 2.3 : (bm * bn == 8192 ? 1.35 : 0.78);
+    const double whole = steps * step_us;
+    double best = whole * 0.9;                    // a cut has to win 10 % of a tile time
+    int best_s = 1;
+    for (int sl = 2; sl <= 16 && steps / sl >= 4; ++sl) {
+        const long long rounds = (rem * sl + 255) / 256;
+        const double cost = (double)rounds * ((steps + sl - 1) / sl) * step_us + 3.0 + 0.4 * sl;
+        if (cost < best) { best = cost; best_s = sl; }
+    }
+    return best_s;
+}
 
 template <int BM, int BN>
 hipError_t launch_t(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) {
@@ -960,12 +976,30 @@ hipError_t p3d_stream_scratch(hipStream_t s, size_t slab_floats, size_t counters
         unsigned* p = nullptr;
         hipError_t e = hipMalloc((void**)&p, want * sizeof(unsigned));
         if (e != hipSuccess) return e;
-        e = hipMemset(p, 0, want * sizeof(unsigned));        // tickets start at zero; every reducer re-zeroes its own
+        // tickets start at zero; every reducer re-zeroes its own.  Zeroed IN STREAM ORDER: a null-stream memset is not ordered
+        // against the launch that follows on a non-blocking stream
+        e = hipMemsetAsync(p, 0, want * sizeof(unsigned), s);
         if (e != hipSuccess) return e;
         sc.cnt = p; sc.counters = want; g_scratch_allocs.push_back(p);
     }
     *slab = sc.slab; *cnt = sc.cnt;
     return hipSuccess;
+}
+
+// Test hook: arrival counters that are not zero although nothing is in flight (every K-sliced launch must leave its counters
+// as it found them); -1 on a HIP error.
+long long p3d_scratch_dirty_counters() {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    std::lock_guard<std::mutex> g(g_scratch_mutex);
+    long long dirty = 0;
+    for (auto& kv : g_scratch) {
+        const Scratch& sc = kv.second;
+        if (!sc.cnt || !sc.counters) continue;
+        std::vector<unsigned> h(sc.counters);
+        if (hipMemcpy(h.data(), sc.cnt, sc.counters * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        for (unsigned v : h) dirty += v != 0;
+    }
+    return dirty;
 }
 
 void p3d_release_scratch() {
@@ -1134,12 +1168,11 @@ hipError_t launch_group_t(IgemmGroupArgs& g, const long long* tiles, hipStream_t
 
 // Would the tail of this single launch be cut into K-slices (then it goes out through the grouped kernel)?
 bool p3d_igemm2_tail_split(const IgemmArgs& a, const P3dIgemmPlan& pl) {
-    if (a.at_mode || a.ngate || a.statpart || pl.splits > 1 || !tail_split_enabled()) return false;
+    if (a.at_mode || a.ngate || pl.splits > 1 || !tail_split_enabled()) return false;
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const long long tiles = ((M + pl.bm - 1) / pl.bm) * ((a.Nc + pl.bn - 1) / pl.bn);
-    const long long rem = tiles % 256;
     const int steps = a.ntaps * ((a.K + BK - 1) / BK);
-    return tiles >= 256 && rem > 0 && std::min<long long>(std::min<long long>(16, 256 / rem), steps / 4) >= 2;
+    return tiles >= 256 && tail_slices(tiles % 256, steps, pl.bm, pl.bn) >= 2;
 }
 
 hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan& pl, hipStream_t s) {
@@ -1181,15 +1214,14 @@ hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan
     // Tail of the last wave: with one block per CU a launch of T tiles takes ceil(T / 256) rounds, and a last round that fills
     // a small part of the chip costs a whole tile time (deconv3's input gradient at 8 clips: 784 tiles of 128x128 = 3.06
     // rounds).  The tiles of that round become a class of their own, K-sliced so that its blocks fill the round.
-    if (nc >= 1 && nc < P3D_IGEMM_CLASSES && g.cls[nc - 1].nsplit == 1 && !g.cls[nc - 1].statpart) {
+    if (nc >= 1 && nc < P3D_IGEMM_CLASSES && g.cls[nc - 1].nsplit == 1) {
         long long blocks = 0;
         for (int q = 0; q < nc; ++q) blocks += tiles[q] * g.cls[q].nsplit;
         const long long rem = blocks % 256;
         const IgemmClass& last = g.cls[nc - 1];
         const int steps = last.ntaps * ((g.common.K + BK - 1) / BK);
-        int sl = rem > 0 ? (int)std::min<long long>(16, 256 / rem) : 1;
-        sl = std::min(sl, steps / 4);
-        if (blocks >= 256 && rem > 0 && rem < tiles[nc - 1] && sl >= 2 && tail_split_enabled()) {
+        const int sl = tail_slices(rem, steps, pl.bm, pl.bn);
+        if (blocks >= 256 && rem > 0 && rem < tiles[nc - 1] && sl >= 2) {
             g.cls[nc] = last;
             g.cls[nc].tile0 = (int)(tiles[nc - 1] - rem);
             g.cls[nc].nsplit = sl;

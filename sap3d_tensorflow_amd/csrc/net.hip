@@ -2738,6 +2738,8 @@ int p3d_set_pointwise_fp16(p3d_handle* h, int enable) {
     API_END
 }
 
+int64_t p3d_debug_dirty_counters(void) { return (int64_t)p3d_scratch_dirty_counters(); }
+
 int p3d_debug_force_plan(int igemm_tile, int igemm_splits, int wgrad_tm, int wgrad_tn) {
     p3d_igemm2_override(igemm_tile, igemm_splits);
     p3d_wgrad2_force_tile(wgrad_tm, wgrad_tn);

@@ -178,6 +178,7 @@ inline int p3d_igemm2_mtiles(const IgemmArgs& a, const P3dIgemmPlan& pl) {
 // Per-stream scratch for K-sliced launches (partial tiles + arrival counters).  Launches on one stream run in order, so
 // they share it; the buffers only grow, and an outgrown buffer stays allocated (captured graphs may still name it).
 hipError_t p3d_stream_scratch(hipStream_t s, size_t slab_floats, size_t counters, float** slab, unsigned** cnt);
+long long p3d_scratch_dirty_counters();      // test hook: non-zero arrival counters with nothing in flight (must be 0)
 void p3d_release_scratch();     // frees every scratch buffer (process shutdown; no launch may be in flight)
 
 // Weight-gradient launch: dW[widx][k][n] += sum_m Xg[m+tap, k] * dY[m, n]

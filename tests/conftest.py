@@ -10,3 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(autouse=True)
+def _k_slice_scratch_stays_clean(request):
+    """After every GPU test: no arrival counter of the K-slice exchange may be left non-zero (a launch that does would hand a
+    premature "last arriver" to whichever launch uses that counter next -- in another session of the same process)."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    from sap3d_tensorflow_amd import lib
+    dirty = lib().p3d_debug_dirty_counters()
+    assert dirty == 0, "%d arrival counters left non-zero by %s" % (dirty, request.node.nodeid)

@@ -146,6 +146,30 @@ def test_filter_gradient_tile_shapes(tile, xs, k, co):
         lib().p3d_debug_force_plan(-1, 0, 0, 0)
 
 
+@pytest.mark.parametrize("tile,xs,co", [(1, (1, 8, 56, 112, 32), 64), (0, (1, 4, 56, 112, 32), 64), (2, (1, 8, 56, 112, 32), 128),
+                                         (1, (2, 4, 56, 100, 16), 64)])
+def test_conv_last_round_more_than_half_full(tile, xs, co):
+    """392 (or 350) tiles = 1.53 rounds: the 136 tiles of the last round are cut into several K-slices that themselves take
+    more than one round of blocks (conv_igemm2.hip, tail_slices)."""
+    from sap3d_tensorflow_amd import lib, ops
+    k, s = (3, 3, 3), (1, 1, 1)
+    rng = np.random.default_rng(23)
+    x = rnd(rng, xs)
+    w = rnd(rng, k + (xs[4], co)) * 0.1
+    b = rnd(rng, (co,))
+    want = nn.conv3d_forward(x.astype(np.float64), w.astype(np.float64), s) + b
+    dy = rnd(rng, want.shape)
+    want_dx = nn.conv3d_backward_input(dy.astype(np.float64), w.astype(np.float64), s, xs)
+    lib().p3d_debug_force_plan(tile, 0, 0, 0)
+    try:
+        got = ops.conv3d(x, w, s, bias=b)
+        got_dx = ops.conv3d_backprop_input(xs, w, dy, s)
+    finally:
+        lib().p3d_debug_force_plan(-1, 0, 0, 0)
+    close(got, want)
+    close(got_dx, want_dx)
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2])
 def test_conv_last_round_is_k_sliced(tile):
     """A launch whose tile count is a little over a multiple of the 256 CUs: the tiles of the last round go out as a K-sliced
