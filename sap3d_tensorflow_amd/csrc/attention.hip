@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(AttnMixArgs a) {
     __syncthreads();
     // per-block partial; the last arriving block adds them in block order (no atomics)
     __shared__ int last_flag;
-    if (threadIdx.x == 0) a.part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    if (!p3d_last_block(a.counter, gridDim.x, &last_flag)) return;
+    if (threadIdx.x == 0) p3d_store_wt(a.part, blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]));
+    if (!p3d_last_block_wt(a.counter, gridDim.x, &last_flag)) return;
     float t = 0.f;
     for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += a.part[b];
 #pragma unroll

@@ -234,8 +234,8 @@ __global__ __launch_bounds__(384) void bwd_k7_kernel(CbamArgs a) {
     }
     // per-block partials; the last arriving block adds them in block order (no atomics)
     __shared__ int last_flag;
-    if (tap < 343) { a.k7part[((size_t)blockIdx.x * 343 + tap) * 2] = a0; a.k7part[((size_t)blockIdx.x * 343 + tap) * 2 + 1] = a1; }
-    if (!p3d_last_block(a.k7counter, gridDim.x, &last_flag)) return;
+    if (tap < 343) { p3d_store_wt(a.k7part, ((size_t)blockIdx.x * 343 + tap) * 2, a0); p3d_store_wt(a.k7part, ((size_t)blockIdx.x * 343 + tap) * 2 + 1, a1); }
+    if (!p3d_last_block_wt(a.k7counter, gridDim.x, &last_flag)) return;
     if (tap < 343) {
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll 4

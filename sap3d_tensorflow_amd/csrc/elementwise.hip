@@ -453,8 +453,8 @@ __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* pred, const
     __syncthreads();
     // per-block partial, then the last arriving block adds the partials in block order (no atomics: the loss is
     // bit-reproducible)
-    if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (!p3d_last_block(counter, gridDim.x, &last_flag)) return;
+    if (threadIdx.x == 0) p3d_store_wt(part, blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    if (!p3d_last_block_wt(counter, gridDim.x, &last_flag)) return;
     double t = 0.0;
     for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += part[b];
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
@@ -536,13 +536,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* dy, int ld, lo
     __shared__ int last_flag;
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
     float acc = 0.f;
-    if (c < C)
-        for (long long row = blockIdx.x; row < M; row += gridDim.x) acc += dy[row * ld + c];
-    if (c < C) part[(size_t)blockIdx.x * C + c] = acc;
-    if (!p3d_last_block(counters + blockIdx.y, gridDim.x, &last_flag)) return;
+    if (c < C) {
+        // row order as before, eight rows' loads in flight
+        long long row = blockIdx.x;
+        const long long st = gridDim.x;
+        for (; row + 7 * st < M; row += 8 * st) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dy[(row + u * st) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; row < M; row += st) acc += dy[row * ld + c];
+        p3d_store_wt(part, (size_t)blockIdx.x * C + c, acc);
+    }
+    if (!p3d_last_block_wt(counters + blockIdx.y, gridDim.x, &last_flag)) return;
     if (c >= C) return;
     float t = 0.f;
-    for (unsigned b = 0; b < gridDim.x; ++b) t += part[(size_t)b * C + c];
+    unsigned b = 0;
+    for (; b + 7 < gridDim.x; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; b < gridDim.x; ++b) t += part[(size_t)b * C + c];
     out[c] += t;
 }
 
@@ -578,9 +597,9 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
     if (threadIdx.x < L) {
         float4 t = red[threadIdx.x];
         for (int r = 1; r < R; ++r) { const float4 v = red[r * L + threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-        *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * C + threadIdx.x * 4) = t;
+        p3d_store_wt4(part, (size_t)blockIdx.x * C + threadIdx.x * 4, t);      // write-through: no release fence below
     }
-    if (!p3d_last_block(counters, gridDim.x, &last_flag)) return;
+    if (!p3d_last_block_wt(counters, gridDim.x, &last_flag)) return;
     acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live)
         for (unsigned b = rs; b < gridDim.x; b += R) {
@@ -877,7 +896,7 @@ hipError_t p3d_colsum(const float* dy, int ld, long M, int C, float* out, hipStr
         return hipGetLastError();
     }
     long long bx = (M + 63) / 64;
-    if (bx > 512) bx = 512;
+    if (bx > 128) bx = 128;
     if (bx < 1) bx = 1;
     const unsigned gy = (unsigned)((C + 255) / 256);
     float* slab = nullptr; unsigned* cnt = nullptr;

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void head_bwd_filter_kernel(HeadArgs a) {
         if (threadIdx.x < C) {
             float s = 0.f;
             for (int l = 0; l < lanes; ++l) s += red[l * C + threadIdx.x];
-            a.part[((size_t)blockIdx.x * 28 + q) * C + threadIdx.x] = s;
+            p3d_store_wt(a.part, ((size_t)blockIdx.x * 28 + q) * C + threadIdx.x, s);
         }
         __syncthreads();
     }
@@ -217,11 +217,11 @@ __global__ __launch_bounds__(256) void head_bwd_filter_kernel(HeadArgs a) {
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int l = 0; l < lanes; ++l) s += red[l * C];
-        a.part[((size_t)blockIdx.x * 28 + 27) * C] = s;
+        p3d_store_wt(a.part, ((size_t)blockIdx.x * 28 + 27) * C, s);
     }
     // the last arriving block adds every block's partial filter gradient in block order (no atomics)
     __shared__ int last_flag;
-    if (!p3d_last_block(a.counter, gridDim.x, &last_flag)) return;
+    if (!p3d_last_block_wt(a.counter, gridDim.x, &last_flag)) return;
     for (int i = threadIdx.x; i < 27 * C + 1; i += blockDim.x) {
         const size_t slot = i < 27 * C ? (size_t)i : (size_t)27 * C;
         float t = 0.f;
@@ -270,7 +270,6 @@ __global__ __launch_bounds__(256) void head_bwd_filter4_kernel(HeadArgs a) {
                     }
         }
     }
-    float* mine = a.part + (size_t)blockIdx.x * 28 * C;
 #pragma unroll
     for (int q = 0; q < 27; ++q) {
         red[threadIdx.x] = live ? acc[q] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -278,7 +277,7 @@ __global__ __launch_bounds__(256) void head_bwd_filter4_kernel(HeadArgs a) {
         if (threadIdx.x < L) {
             float4 s = red[threadIdx.x];
             for (int r = 1; r < R; ++r) { const float4 v = red[r * L + threadIdx.x]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-            *reinterpret_cast<float4*>(mine + q * C + threadIdx.x * 4) = s;
+            p3d_store_wt4(a.part, (size_t)blockIdx.x * 28 * C + q * C + threadIdx.x * 4, s);      // write-through: see p3d_last_block_wt
         }
         __syncthreads();
     }
@@ -287,20 +286,20 @@ __global__ __launch_bounds__(256) void head_bwd_filter4_kernel(HeadArgs a) {
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int r = 0; r < R; ++r) s += red[r * L].x;
-        mine[27 * C] = s;
+        p3d_store_wt(a.part, (size_t)blockIdx.x * 28 * C + 27 * C, s);
     }
     const int nvals = 27 * C + 1;
     const unsigned ngroups = (gridDim.x + HEAD_FOLD - 1) / HEAD_FOLD, group = blockIdx.x / HEAD_FOLD;
     const unsigned first = group * HEAD_FOLD, in_group = min((unsigned)HEAD_FOLD, gridDim.x - first);
     float* gpart = a.part + (size_t)gridDim.x * 28 * C;
-    if (!p3d_last_block(a.counter + 1 + group, in_group, &last_flag)) return;
+    if (!p3d_last_block_wt(a.counter + 1 + group, in_group, &last_flag)) return;
     for (int i = threadIdx.x; i < nvals; i += blockDim.x) {
         float t = 0.f;
 #pragma unroll 8
         for (unsigned b = 0; b < in_group; ++b) t += a.part[(size_t)(first + b) * 28 * C + i];
-        gpart[(size_t)group * 28 * C + i] = t;
+        p3d_store_wt(gpart, (size_t)group * 28 * C + i, t);
     }
-    if (!p3d_last_block(a.counter, ngroups, &last_flag)) return;
+    if (!p3d_last_block_wt(a.counter, ngroups, &last_flag)) return;
     for (int i = threadIdx.x; i < nvals; i += blockDim.x) {
         float t = 0.f;
 #pragma unroll 8
@@ -422,7 +421,7 @@ __global__ __launch_bounds__(256) void headc_bwd_filter_kernel(HeadArgs a) {
         if (threadIdx.x < C) {
             float s = 0.f;
             for (int l = 0; l < lanes; ++l) s += red[l * C + threadIdx.x];
-            a.part[((size_t)blockIdx.x * 28 + q) * C + threadIdx.x] = s;
+            p3d_store_wt(a.part, ((size_t)blockIdx.x * 28 + q) * C + threadIdx.x, s);
         }
         __syncthreads();
     }
@@ -431,11 +430,11 @@ __global__ __launch_bounds__(256) void headc_bwd_filter_kernel(HeadArgs a) {
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int l = 0; l < lanes; ++l) s += red[l * C];
-        a.part[((size_t)blockIdx.x * 28 + 27) * C] = s;
+        p3d_store_wt(a.part, ((size_t)blockIdx.x * 28 + 27) * C, s);
     }
     // the last arriving block adds every block's partial filter gradient in block order (no atomics)
     __shared__ int last_flag;
-    if (!p3d_last_block(a.counter, gridDim.x, &last_flag)) return;
+    if (!p3d_last_block_wt(a.counter, gridDim.x, &last_flag)) return;
     for (int i = threadIdx.x; i < 27 * C + 1; i += blockDim.x) {
         const size_t slot = i < 27 * C ? (size_t)i : (size_t)27 * C;
         float t = 0.f;
