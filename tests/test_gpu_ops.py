@@ -247,3 +247,17 @@ def test_attention_core_forward_and_grads(B, ng, nf, ch):
     close(df, want_df, 1e-4)
     again = ops.attention_core(g, f, h, d_o)
     assert all(np.array_equal(a, b) for a, b in zip((o, dg, df, dh), again))
+
+
+def test_dense_pointwise_conv_at_stage1_size():
+    """A 1x1x1 conv over 50176 rows (conv3 of stage 1 at 8 clips of 16x112x112: 784 tiles of 128x128, two K steps each),
+    forward and input gradient against the oracle."""
+    from sap3d_tensorflow_amd import ops
+    xs = (8, 8, 28, 28, 64)
+    rng = np.random.default_rng(3)
+    x = rnd(rng, xs)
+    w = rnd(rng, (1, 1, 1, 64, 256)) * 0.2
+    want = nn.conv3d_forward(x.astype(np.float64), w.astype(np.float64), (1, 1, 1))
+    close(ops.conv3d(x, w, (1, 1, 1)), want)
+    dy = rnd(rng, want.shape)
+    close(ops.conv3d_backprop_input(xs, w, dy, (1, 1, 1)), nn.conv3d_backward_input(dy.astype(np.float64), w.astype(np.float64), (1, 1, 1), xs))
