@@ -530,9 +530,16 @@ struct p3d_handle {
     hipStream_t stream = nullptr, comm_stream = nullptr, side_stream = nullptr;
     std::vector<hipEvent_t> fork_events;
     hipEvent_t ev_side_done = nullptr, ev_side_bucket = nullptr;
+    // Events that only order this handle's own streams on one device: no system-scope fence when they complete (the default
+    // writes the caches back for the host and for other devices -- tens of microseconds on the main stream at every hand-over
+    // to the side stream; the events that gate the all-reduce and the host keep the default).
+    static unsigned local_event_flags() {
+        static const bool sysfence = [] { const char* e = p3d_tune_env("P3D_TUNE_EVENT_SYSFENCE"); return e && atoi(e); }();
+        return hipEventDisableTiming | (sysfence ? 0u : (unsigned)hipEventDisableSystemFence);
+    }
     hipEvent_t new_fork_event() {
         hipEvent_t e = nullptr;
-        HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&e, local_event_flags()));
         fork_events.push_back(e);
         return e;
     }
@@ -740,7 +747,7 @@ struct p3d_handle {
         if (wq.empty() || c.dry) { wq.clear(); return; }
         if (wq_flushes >= wq_events.size()) {
             hipEvent_t e = nullptr;
-            HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&e, local_event_flags()));
             wq_events.push_back(e);
         }
         hipEvent_t ev = wq_events[wq_flushes++];
