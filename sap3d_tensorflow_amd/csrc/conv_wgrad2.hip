@@ -540,31 +540,59 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const WGroup g) {
         __syncthreads();
         if (!*flag) return;
         const float* slabs = g.slab + (size_t)slot * g.kstride * SLAB;
-#pragma unroll 2
-        for (int i = tid; i < BM * F4R; i += 256) {
-            const int r = i / F4R, c4 = (i - r * F4R) * 4;
-            const float* src = slabs + r * BN + c4;
-            float4 v = *reinterpret_cast<const float4*>(src);
+        // The slabs come from other CUs' write-through stores: every load is a long-latency miss.  Sixteen in flight per lane
+        // (four tile positions x four cuts), added in cut order -- with up to 256 cuts (the stem's filter gradient) the fold
+        // is a large part of the launch.
+        constexpr int PER_LANE = BM * F4R / 256;
+        static_assert(PER_LANE % 4 == 0, "the fold takes four tile positions at a time");
+#pragma unroll 1
+        for (int i0 = 0; i0 < PER_LANE; i0 += 4) {
+            float4 v[4];
+            const float* src[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + (i0 + q) * 256;
+                const int r = i / F4R, c4 = (i - r * F4R) * 4;
+                src[q] = slabs + r * BN + c4;
+                v[q] = *reinterpret_cast<const float4*>(src[q]);
+            }
             int s = 1;
-            for (; s + 3 < p.ksplit; s += 4) {                  // four loads in flight, added in cut order
-                const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)(s + 0) * SLAB);
-                const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)(s + 1) * SLAB);
-                const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)(s + 2) * SLAB);
-                const float4 a3 = *reinterpret_cast<const float4*>(src + (size_t)(s + 3) * SLAB);
-                v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
-                v.x += a1.x; v.y += a1.y; v.z += a1.z; v.w += a1.w;
-                v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w;
-                v.x += a3.x; v.y += a3.y; v.z += a3.z; v.w += a3.w;
+            for (; s + 3 < p.ksplit; s += 4) {
+                float4 t4[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t4[t][q] = *reinterpret_cast<const float4*>(src[q] + (size_t)(s + t) * SLAB);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q].x += t4[t][q].x; v[q].y += t4[t][q].y; v[q].z += t4[t][q].z; v[q].w += t4[t][q].w; }
             }
             for (; s < p.ksplit; ++s) {
-                const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * SLAB);
-                v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
+                float4 t4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t4[q] = *reinterpret_cast<const float4*>(src[q] + (size_t)s * SLAB);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q].x += t4[q].x; v[q].y += t4[q].y; v[q].z += t4[q].z; v[q].w += t4[q].w; }
             }
-            *reinterpret_cast<float4*>(tile + r * LDT + c4) = v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + (i0 + q) * 256;
+                const int r = i / F4R, c4 = (i - r * F4R) * 4;
+                *reinterpret_cast<float4*>(tile + r * LDT + c4) = v[q];
+            }
         }
         if (tid < BN) {
             float t = 0.f;
-            for (int s = 0; s < p.ksplit; ++s) t += slabs[(size_t)s * SLAB + BM * BN + tid];
+            int s = 0;
+            for (; s + 7 < p.ksplit; s += 8) {                  // cut order, eight loads in flight
+                float u[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) u[q] = slabs[(size_t)(s + q) * SLAB + BM * BN + tid];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t += u[q];
+            }
+            for (; s < p.ksplit; ++s) t += slabs[(size_t)s * SLAB + BM * BN + tid];
             bias_lds[tid] = t;
         }
         __syncthreads();
