@@ -290,10 +290,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 // Folds the per-block partial sums in block order (double accumulation, fixed shuffle tree): coef[c] = (sum g / M,
 // sum g*xhat / M) and the BN parameter gradients (each BN parameter is produced exactly once per step, so they are
 // written, not accumulated).
+// LPC lanes per channel (16, or 64 when there are many partials: 100-500 per channel in stages 1-2, where 16 lanes walk them in
+// 6-8 dependent batches of loads -- this kernel sits between the reduce and the apply pass of every large BatchNorm backward).
+template <int LPC>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int two) {
     P3D_CHAIN_PRIO();
-    const int r = threadIdx.x & 15;
-    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int r = threadIdx.x % LPC;
+    const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     const bool ok = c < a.C;
     const double invM = 1.0 / (double)a.M;
     double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -301,14 +304,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int t
         const float2* p1 = reinterpret_cast<const float2*>(a.part1) + c;
         const float2* p2 = reinterpret_cast<const float2*>(a.part2) + c;
 #pragma unroll 4
-        for (int q = r; q < a.nparts; q += 16) {
+        for (int q = r; q < a.nparts; q += LPC) {
             const float2 v = p1[(size_t)q * a.C];
             s1 += (double)v.x; s2 += (double)v.y;
             if (two) { const float2 w = p2[(size_t)q * a.C]; t1 += (double)w.x; t2 += (double)w.y; }
         }
     }
-    s1 = fold16(s1); s2 = fold16(s2);
-    if (two) { t1 = fold16(t1); t2 = fold16(t2); }
+#pragma unroll
+    for (int o = LPC / 2; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o);
+        if (two) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+    }
     if (!ok || r) return;
     a.dbeta1[c] = (float)s1; a.dgamma1[c] = (float)s2;
     a.coef1[2 * c] = (float)(s1 * invM); a.coef1[2 * c + 1] = (float)(s2 * invM);
@@ -715,7 +721,9 @@ hipError_t p3d_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
 }
 
 hipError_t p3d_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 15) / 16), dim3(256), 0, s, a, (a.mode == 2 || a.mode == 3) ? 1 : 0);
+    const int two = (a.mode == 2 || a.mode == 3) ? 1 : 0;
+    if (a.nparts >= 64) hipLaunchKernelGGL(bn_bwd_finalize_kernel<64>, dim3((a.C + 3) / 4), dim3(256), 0, s, a, two);
+    else hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((a.C + 15) / 16), dim3(256), 0, s, a, two);
     return hipGetLastError();
 }
 
