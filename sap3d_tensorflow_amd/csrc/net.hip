@@ -2136,6 +2136,7 @@ struct p3d_handle {
         if (!blocks.empty()) {
             const Act* last = blocks.rbegin()->second.out;
             if (last && last->rows() <= 2048) defer_budget = 130e9;
+            if (const char* e = p3d_tune_env("P3D_TUNE_DEFER_GFLOP")) defer_budget = atof(e) * 1e9;      // A/B runs
         }
         tune_plans();
         plan_zero_arenas();
@@ -2288,6 +2289,7 @@ struct p3d_handle {
         // encoder (unet++, the GN nets) parks its first jobs only, and nothing is parked when the encoder's own launches fill
         // the chip (32x224x224 clips).
         std::vector<std::pair<hipEvent_t, std::function<void(const Ctx&)>>> parked;
+        bool early_adam = false, early_comm = false;
         static const bool no_defer = p3d_tune_env("P3D_DEFER_SIDE") && atoi(p3d_tune_env("P3D_DEFER_SIDE")) == 0;
         const bool defer_on = c.side && !no_defer && defer_release_op > 0 && defer_budget > 0;
         parked_flops = 0;
@@ -2312,15 +2314,14 @@ struct p3d_handle {
                 }
                 static const bool no_split = p3d_tune_env("P3D_SPLIT_ADAM") && atoi(p3d_tune_env("P3D_SPLIT_ADAM")) == 0;     // A/B runs
                 if (with_adam && !no_split) {
+                    // what the first Adam part has to wait for is marked NOW, before the first op's filter gradient goes to the
+                    // side stream; the part itself is enqueued after that op's backward (below), so that the two overlap --
+                    // enqueued here, the filter gradient's fork event would sit behind Adam on the main stream and the tail of
+                    // the step would be Adam, then the filter gradient, then the second Adam part, one after the other
                     HIPCHECK(hipEventRecord(ev_side_early, c.side));
-                    HIPCHECK(hipStreamWaitEvent(c.s, ev_side_early, 0));
-                    if (reduce && comm && !bucket_hook) {
-                        HIPCHECK(hipEventRecord(ev_comm_early, comm_stream));
-                        HIPCHECK(hipStreamWaitEvent(c.s, ev_comm_early, 0));
-                    }
-                    adam_begin(c);
-                    adam_range(c, adam_split, n_train);
-                    adam_done = true;
+                    early_comm = reduce && comm && !bucket_hook;
+                    if (early_comm) HIPCHECK(hipEventRecord(ev_comm_early, comm_stream));
+                    early_adam = true;
                 }
             }
             if (defer_on) {
@@ -2329,6 +2330,14 @@ struct p3d_handle {
             }
             ops[i].bwd(c);
             debug_sync("bwd", ops[i], c);
+            if (early_adam) {
+                early_adam = false;
+                HIPCHECK(hipStreamWaitEvent(c.s, ev_side_early, 0));
+                if (early_comm) HIPCHECK(hipStreamWaitEvent(c.s, ev_comm_early, 0));
+                adam_begin(c);
+                adam_range(c, adam_split, n_train);
+                adam_done = true;
+            }
             {
                 // gradients at flat offsets >= lo belong to ops i.. only, so they are final now.  The walk (and the flush
                 // of queued filter gradients at every bucket boundary) runs with or without a communicator, so that the
