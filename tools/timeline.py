@@ -24,13 +24,17 @@ def main():
     rows = list(csv.DictReader(f))
     for r in rows:
         r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp']); r['q'] = r['Queue_Id']
-    adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+    # one period of the steady state: from the first kernel of step k's forward (the stem's padding pass) to the first kernel of
+    # step k + 1's -- the optimiser no longer marks a step boundary (its ranges run inside the backward pass)
+    rows.sort(key=lambda r: r['s'])
+    starts = [i for i, r in enumerate(rows) if 'stem_pad_kernel' in r['Kernel_Name']]
     loss = [i for i, r in enumerate(rows) if 'smooth_l1' in r['Kernel_Name']]
-    prev_adam = max(a for a in adam if a < loss[k])
-    next_adams = [a for a in adam if a > loss[k]][:2]
-    step = rows[prev_adam + 1:next_adams[-1] + 1]
+    step = rows[starts[k]:starts[k + 1]]
+    loss = [i - starts[k] for i in loss if starts[k] <= i < starts[k + 1]] or [0]
+    rows = step
+    k = 0
     t0 = min(r['s'] for r in step); t1 = max(r['e'] for r in step)
-    print("step %d of the trace: %.3f ms, %d dispatches; loss kernel at %.3f ms" % (k, (t1 - t0) / 1e6, len(step), (rows[loss[k]]['s'] - t0) / 1e6))
+    print("step %d of the trace: %.3f ms, %d dispatches; loss kernel at %.3f ms" % (k, (t1 - t0) / 1e6, len(step), (rows[loss[0]]['s'] - t0) / 1e6))
     byq = collections.defaultdict(list)
     for r in step:
         byq[r['q']].append(r)
