@@ -1031,7 +1031,9 @@ P3dIgemmPlan heuristic_plan(const IgemmArgs& a) {
     const int steps = a.ntaps * kchunks;
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((a.Nc + bn - 1) / bn); };
     const long long want = 384;
-    if (a.Nc > 64 && tiles(128, 128) >= want) { pl.bm = 128; pl.bn = 128; }
+    // (with one to four K steps a tile is mostly prologue and epilogue, and twice as many 128x64 tiles quantise better on the
+    // chip: stage 1's 64 -> 256 convs 44.5 -> 40.5 us, their 256 <- 64 input gradients 51 -> 45.6 us; tools/op_times.py --igemm-tile)
+    if (a.Nc > 64 && tiles(128, 128) >= want && steps > 4) { pl.bm = 128; pl.bn = 128; }
     else if (tiles(128, 64) >= want || (a.Nc <= 64 && tiles(128, 64) >= 128)) { pl.bm = 128; pl.bn = 64; }
     else { pl.bm = 64; pl.bn = 64; }
     pl.splits = 1;
