@@ -1038,7 +1038,7 @@ P3dIgemmPlan heuristic_plan(const IgemmArgs& a) {
     else { pl.bm = 64; pl.bn = 64; }
     pl.splits = 1;
     const long long t = tiles(pl.bm, pl.bn);
-    if (pl.bm == 64 && pl.bn == 64 && t < 150 && steps >= 8) {
+    if (pl.bm == 64 && pl.bn == 64 && t < 256 && steps >= 8) {       // (196 tiles x 36 steps, stage 2's 1x3x3 convs: two slices, 38.4 -> 35.5 us)
         // Measured on MI355X (tools/micro/conv_chain.hip, M = 784 rows, cold weights): a 64x64 step costs ~0.78 us while
         // at most one block sits on a CU and proportionally more beyond that; cutting K into s slices costs ~3 + 0.4 s us
         // (write-through slab stores, ticket, the last arriver's s slab reads, 16 loads in flight per lane).  Pick the

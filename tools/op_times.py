@@ -17,12 +17,13 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=112)
     ap.add_argument("--igemm-tile", type=int, default=-1, help="force the conv tile everywhere: 0 = 64x64, 1 = 128x64, 2 = 128x128")
+    ap.add_argument("--igemm-splits", type=int, default=0, help="force the K-slice count of the convs (where a problem allows it)")
     ap.add_argument("--wgrad-tile", default=None, help="force the filter-gradient tile of single-problem launches, e.g. 128x128")
     a = ap.parse_args()
     from sap3d_tensorflow_amd import P3DSession, lib, synthetic as law
-    if a.wgrad_tile or a.igemm_tile >= 0:
+    if a.wgrad_tile or a.igemm_tile >= 0 or a.igemm_splits > 0:
         tm, tn = (int(v) for v in a.wgrad_tile.split("x")) if a.wgrad_tile else (0, 0)
-        lib().p3d_debug_force_plan(a.igemm_tile, 0, tm, tn)
+        lib().p3d_debug_force_plan(a.igemm_tile, a.igemm_splits, tm, tn)
     sess = P3DSession(a.structure, batch=a.batch, frames=a.frames, height=a.size, width=a.size, seed=0)
     sess.set_adam(1e-4)
     shape = (a.batch, a.frames, a.size, a.size)
