@@ -698,8 +698,9 @@ WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
     // blocks and lost 0.2-3.6 ms per step on every workload although each filter gradient alone was faster.
     if (a.pair) return best_for(64, 64);
     const bool forced = g_force_tm != 0;
-    // (from 4096 positions: deconv2's filter gradient at 8 clips of 16x112x112, 6272 positions x 18 taps, 493 -> 359 us)
-    const bool busy = other_tiles == 0 && M >= 4096 && a.Nc >= 128 && !wtune().no_rect && !forced;
+    // (from 2048 positions: deconv2's filter gradient at 8 clips of 16x112x112, 6272 positions x 18 taps, 493 -> 359 us; deconv1's
+    // at 32x224x224, 3136 positions, 473 -> 340 us)
+    const bool busy = other_tiles == 0 && M >= 2048 && a.Nc >= 128 && !wtune().no_rect && !forced;
     if (busy) return best_for(64, 128);
     WPlan best = best_for(64, 64);
     if (other_tiles == 0) {
