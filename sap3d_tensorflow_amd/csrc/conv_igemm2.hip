@@ -1034,7 +1034,10 @@ P3dIgemmPlan heuristic_plan(const IgemmArgs& a) {
     // (with one to four K steps a tile is mostly prologue and epilogue, and twice as many 128x64 tiles quantise better on the
     // chip: stage 1's 64 -> 256 convs 44.5 -> 40.5 us, their 256 <- 64 input gradients 51 -> 45.6 us; tools/op_times.py --igemm-tile)
     // 128x128 from 512 tiles (two per CU): 392 tiles -- stage 2's 1x3x3 convs at 32x224x224 -- run 20 % faster as 784 of 128x64
-    if (a.Nc > 64 && tiles(128, 128) >= 512 && steps > 4) { pl.bm = 128; pl.bn = 128; }
+    // ... and not when the last 128-column tile would be half empty or worse (192 output channels, the unet++ head's x_1_1 input
+    // gradient: 2707 us as two column tiles of 128, 2165 us as three of 64)
+    const bool ragged128 = (a.Nc % 128) != 0 && (a.Nc % 128) <= 64;
+    if (a.Nc > 64 && tiles(128, 128) >= 512 && steps > 4 && !ragged128) { pl.bm = 128; pl.bn = 128; }
     else if (tiles(128, 64) >= want || (a.Nc <= 64 && tiles(128, 64) >= 128)) { pl.bm = 128; pl.bn = 64; }
     else { pl.bm = 64; pl.bn = 64; }
     pl.splits = 1;
