@@ -1,3 +1,6 @@
+"""Compare the planner's choice with forced plans, per op: python tools/plan_sweep.py <dir> <igemm|wgrad> <min gain us> <plan tag> <forced tags...>
+where <dir>/t<tag>.txt are outputs of `tools/op_times.py . --igemm-tile T` (or --wgrad-tile / --igemm-splits); prints the ops on
+which a forced plan beats the planner by more than the threshold."""
 import re,collections,sys
 d=sys.argv[1]; kind=sys.argv[2]; thr=float(sys.argv[3])
 T=sys.argv[4:]
