@@ -106,6 +106,42 @@ def test_config2_forward_backward(ref_params):
     s.close()
 
 
+@pytest.mark.parametrize("block_id", [0, 1, 2, 3, 4])
+def test_bottlenecks_at_batch8_against_the_oracle(ref_params, block_id):
+    """Single bottlenecks of the reference architecture at the batch of configs[2] (8 clips of 16x112x112: 50176 positions in
+    stage 1, 6272 in stage 2) through p3d_block_forward against the oracle's Bottleneck -- the launch shapes the train step uses:
+    tiles over several rounds with K-sliced tail classes, the BatchNorm-statistics epilogue feeding the large-tensor
+    BatchNorm, ST_B's sibling convs as one grouped launch, the strided first block of stage 2."""
+    from oracle import nn
+    from sap3d_tensorflow_amd import P3DSession
+    cfg = p3d.REFERENCE_CFG
+    p64 = {k: v.astype(np.float64) for k, v in ref_params.items()}
+    s = P3DSession('unet', batch=8)
+    s.load(ref_params)
+    b = cfg.base
+    stage = 0 if block_id < 3 else 1
+    first = block_id in (0, 3)
+    planes = (b, 2 * b)[stage]
+    inplanes = b if block_id == 0 else (4 * b if first else 4 * planes)
+    ishape, _ = s.block_shapes(block_id)
+    assert ishape[0] == 8 and ishape[4] == inplanes
+    x = np.random.default_rng(2).standard_normal(ishape).astype(np.float32)
+    got = s.block_forward(block_id, x)
+    s.close()
+    names = list(p64)
+    k0 = names.index('conv3_%d_1' % block_id)
+    bn = next(n for n in names[k0:] if n.startswith('batch_normalization') and n.endswith('/gamma')).split('/')[0]
+    g = p3d.Graph(p64, dtype=np.float64, create=False)
+    g._uniq['batch_normalization'] = int(bn.split('_')[-1]) if '_' in bn[len('batch_normalization'):] else 0
+    X = nn.Var(x.astype(np.float64))
+    if first:
+        want = p3d.make_block(g, X, planes, 1, inplanes, block_id, stride=2 if stage > 0 else 1).infer().data
+    else:
+        want = p3d.Bottleneck(g, X, inplanes, planes, n_s=block_id).infer().data
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)
+
+
 @pytest.mark.parametrize("structure,shape,step,tol,first_group", [
     ("unet", (8, 16, 112, 112), 2e-5, 8e-2, 0),       # BASELINE.json configs[2]: batch 8, 16x112x112
     ("unet", (1, 32, 224, 224), 2e-5, 8e-2, 0),       # the clip shape of configs[4] (32 frames of 224x224), one clip
