@@ -261,3 +261,20 @@ def test_dense_pointwise_conv_at_stage1_size():
     close(ops.conv3d(x, w, (1, 1, 1)), want)
     dy = rnd(rng, want.shape)
     close(ops.conv3d_backprop_input(xs, w, dy, (1, 1, 1)), nn.conv3d_backward_input(dy.astype(np.float64), w.astype(np.float64), (1, 1, 1), xs))
+
+
+@pytest.mark.parametrize("k,ci,co", [((1, 1, 1), 64, 256), ((1, 3, 3), 64, 64), ((3, 1, 1), 64, 64), ((1, 1, 1), 256, 64)])
+def test_filter_gradients_at_stage1_size(k, ci, co):
+    """Filter (and bias) gradients over 50176 positions (stage 1 at 8 clips of 16x112x112): cut counts, block order and cut
+    folds of the real step's launches, against the oracle."""
+    from sap3d_tensorflow_amd import ops
+    xs = (8, 8, 28, 28, ci)
+    rng = np.random.default_rng(11 + ci + co + k[1])
+    x = rnd(rng, xs)
+    dy = rnd(rng, xs[:4] + (co,))
+    want = nn.conv3d_backward_filter(x.astype(np.float64), dy.astype(np.float64), k + (ci, co), (1, 1, 1))
+    got, db = ops.conv3d_backprop_filter(x, k + (ci, co), dy, (1, 1, 1), with_bias=True)
+    close(got, want)
+    close(db, dy.astype(np.float64).reshape(-1, co).sum(0))
+    again, _ = ops.conv3d_backprop_filter(x, k + (ci, co), dy, (1, 1, 1), with_bias=True)
+    assert np.array_equal(got, again)
