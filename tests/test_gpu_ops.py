@@ -278,3 +278,21 @@ def test_filter_gradients_at_stage1_size(k, ci, co):
     close(db, dy.astype(np.float64).reshape(-1, co).sum(0))
     again, _ = ops.conv3d_backprop_filter(x, k + (ci, co), dy, (1, 1, 1), with_bias=True)
     assert np.array_equal(got, again)
+
+
+def test_conv3d_transpose_at_deconv3_size():
+    """conv3d_transpose [3,3,3] stride 2 over the lattice of deconv3 at 8 clips of 16x112x112 (8 x 8x28x28 -> 16x56x56, 128 output
+    channels; 32 input channels instead of 256 so that the float64 oracle finishes in seconds): the eight stride residue classes
+    as one grouped launch of several rounds, against the oracle."""
+    from sap3d_tensorflow_amd import ops
+    xs, k, co, s = (8, 8, 28, 28, 32), (3, 3, 3), 128, (2, 2, 2)
+    rng = np.random.default_rng(41)
+    x = rnd(rng, xs)
+    kern = rnd(rng, k + (co, xs[4])) * 0.1
+    b = rnd(rng, (co,))
+    t = nn.Tape()
+    want = nn.conv3d_transpose(t, nn.Var(x.astype(np.float64)), nn.Var(kern.astype(np.float64)), s, nn.Var(b.astype(np.float64))).data
+    got = ops.conv3d_transpose(x, kern, s, bias=b)
+    assert got.shape == want.shape
+    close(got, want)
+    assert np.array_equal(got, ops.conv3d_transpose(x, kern, s, bias=b))
