@@ -30,7 +30,19 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(CbamArgs a) {
     const int r0 = ch * per, r1 = min(R, r0 + per);
     for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
         float s = 0.f, m = -INFINITY, t = 0.f;
-        for (int r = r0; r < r1; ++r) {
+        int r = r0;
+        for (; r + 7 < r1; r += 8) {               // eight rows' loads in flight; rows are still merged in order
+            float v8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v8[q] = a.x[((long long)n * R + r + q) * a.ld + c];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = v8[q];
+                s += v;
+                if (v > m) { m = v; t = 1.f; } else if (v == m) t += 1.f;
+            }
+        }
+        for (; r < r1; ++r) {
             const float v = a.x[((long long)n * R + r) * a.ld + c];
             s += v;
             if (v > m) { m = v; t = 1.f; } else if (v == m) t += 1.f;
@@ -62,8 +74,10 @@ __global__ __launch_bounds__(256) void chan_hidden_kernel(CbamArgs a) {
     {
         const int u = threadIdx.x & 7, sl = threadIdx.x >> 3, j = j0 + u;
         float sa = 0.f, sb = 0.f;
-        if (j < a.Ch)
+        if (j < a.Ch) {
+#pragma unroll 8
             for (int c = sl; c < a.C; c += 32) { const float w = a.k0[(long long)c * a.Ch + j]; sa += avg[c] * w; sb += mx[c] * w; }
+        }
         part[(sl * 8 + u) * 2] = sa; part[(sl * 8 + u) * 2 + 1] = sb;
     }
     __syncthreads();
@@ -87,6 +101,7 @@ __global__ __launch_bounds__(256) void chan_out_kernel(CbamArgs a) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < a.C) {
         float o = 2.f * a.b1[c];
+#pragma unroll 16
         for (int j = 0; j < a.Ch; ++j) o += h[j] * a.k1[(long long)j * a.C + c];
         a.cs[(long long)n * a.C + c] = sigm(o);
     }
@@ -112,7 +127,8 @@ __global__ __launch_bounds__(256) void spat_pool_kernel(CbamArgs a) {
     }
 }
 
-// thread per position: 7x7x7 SAME conv over the 2-channel map, sigmoid
+// eight lanes per position (lane k < 7 takes the kernel plane kd = k; the stage-3 maps have 784 positions, a thread per
+// position left the chip to four blocks): 7x7x7 SAME conv over the 2-channel map, planes folded by a fixed shuffle tree, sigmoid
 __global__ __launch_bounds__(256) void spat_conv_kernel(CbamArgs a) {
     P3D_CHAIN_PRIO();
     __shared__ float kw[686];
@@ -120,28 +136,38 @@ __global__ __launch_bounds__(256) void spat_conv_kernel(CbamArgs a) {
     __syncthreads();
     const int R = a.D * a.H * a.W;
     const long long M = (long long)a.N * R;
-    for (long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += (long long)gridDim.x * blockDim.x) {
-        long long t = pos;
-        const int w = (int)(t % a.W); t /= a.W;
-        const int h = (int)(t % a.H); t /= a.H;
-        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+    const int kd = threadIdx.x & 7;
+    for (long long p0 = (long long)blockIdx.x * 32; p0 < M; p0 += (long long)gridDim.x * 32) {
+        const long long pos = p0 + (threadIdx.x >> 3);
         float acc = 0.f;
-        for (int kd = 0; kd < 7; ++kd) {
+        if (pos < M && kd < 7) {
+            long long t = pos;
+            const int w = (int)(t % a.W); t /= a.W;
+            const int h = (int)(t % a.H); t /= a.H;
+            const int d = (int)(t % a.D); const int n = (int)(t / a.D);
             const int id = d + kd - 3;
-            if ((unsigned)id >= (unsigned)a.D) continue;
-            for (int kh = 0; kh < 7; ++kh) {
-                const int ih = h + kh - 3;
-                if ((unsigned)ih >= (unsigned)a.H) continue;
-                for (int kk = 0; kk < 7; ++kk) {
-                    const int iw = w + kk - 3;
-                    if ((unsigned)iw >= (unsigned)a.W) continue;
-                    const float* sp = a.sp + ((((long long)n * a.D + id) * a.H + ih) * a.W + iw) * 2;
-                    const float* k = kw + ((kd * 7 + kh) * 7 + kk) * 2;
-                    acc += sp[0] * k[0] + sp[1] * k[1];
+            if ((unsigned)id < (unsigned)a.D) {
+                for (int kh = 0; kh < 7; ++kh) {
+                    const int ih = h + kh - 3;
+                    if ((unsigned)ih >= (unsigned)a.H) continue;
+                    // the seven taps of a kernel row: loads first (taps outside the map read as 0), sums in tap order
+                    const float* row = a.sp + (((long long)n * a.D + id) * a.H + ih) * a.W * 2;
+                    float2 v7[7];
+#pragma unroll
+                    for (int kk = 0; kk < 7; ++kk) {
+                        const int iw = w + kk - 3;
+                        v7[kk] = (unsigned)iw < (unsigned)a.W ? *reinterpret_cast<const float2*>(row + iw * 2) : make_float2(0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 7; ++kk) {
+                        const float* k = kw + ((kd * 7 + kh) * 7 + kk) * 2;
+                        if ((unsigned)(w + kk - 3) < (unsigned)a.W) acc += v7[kk].x * k[0] + v7[kk].y * k[1];
+                    }
                 }
             }
         }
-        a.ss[pos] = sigm(acc);
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+        if (pos < M && kd == 0) a.ss[pos] = sigm(acc);
     }
 }
 
@@ -164,7 +190,8 @@ __global__ __launch_bounds__(256) void bwd_dpre_kernel(CbamArgs a) {
     }
 }
 
-// thread per position: dsp[pos][ch] = sum_taps dpre[pos - tap + 3] * K[tap][ch]   (transpose of the SAME conv)
+// eight lanes per position (lane k < 7: kernel plane kd = k): dsp[pos][ch] = sum_taps dpre[pos - tap + 3] * K[tap][ch]
+// (transpose of the SAME conv), planes folded by a fixed shuffle tree
 __global__ __launch_bounds__(256) void bwd_spat_conv_kernel(CbamArgs a) {
     P3D_CHAIN_PRIO();
     __shared__ float kw[686];
@@ -172,28 +199,38 @@ __global__ __launch_bounds__(256) void bwd_spat_conv_kernel(CbamArgs a) {
     __syncthreads();
     const int R = a.D * a.H * a.W;
     const long long M = (long long)a.N * R;
-    for (long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += (long long)gridDim.x * blockDim.x) {
-        long long t = pos;
-        const int w = (int)(t % a.W); t /= a.W;
-        const int h = (int)(t % a.H); t /= a.H;
-        const int d = (int)(t % a.D); const int n = (int)(t / a.D);
+    const int kd = threadIdx.x & 7;
+    for (long long p0 = (long long)blockIdx.x * 32; p0 < M; p0 += (long long)gridDim.x * 32) {
+        const long long pos = p0 + (threadIdx.x >> 3);
         float a0 = 0.f, a1 = 0.f;
-        for (int kd = 0; kd < 7; ++kd) {
+        if (pos < M && kd < 7) {
+            long long t = pos;
+            const int w = (int)(t % a.W); t /= a.W;
+            const int h = (int)(t % a.H); t /= a.H;
+            const int d = (int)(t % a.D); const int n = (int)(t / a.D);
             const int od = d - kd + 3;
-            if ((unsigned)od >= (unsigned)a.D) continue;
-            for (int kh = 0; kh < 7; ++kh) {
-                const int oh = h - kh + 3;
-                if ((unsigned)oh >= (unsigned)a.H) continue;
-                for (int kk = 0; kk < 7; ++kk) {
-                    const int ow = w - kk + 3;
-                    if ((unsigned)ow >= (unsigned)a.W) continue;
-                    const float g = a.dpre[(((long long)n * a.D + od) * a.H + oh) * a.W + ow];
-                    const float* k = kw + ((kd * 7 + kh) * 7 + kk) * 2;
-                    a0 += g * k[0]; a1 += g * k[1];
+            if ((unsigned)od < (unsigned)a.D) {
+                for (int kh = 0; kh < 7; ++kh) {
+                    const int oh = h - kh + 3;
+                    if ((unsigned)oh >= (unsigned)a.H) continue;
+                    const float* row = a.dpre + (((long long)n * a.D + od) * a.H + oh) * a.W;
+                    float g7[7];
+#pragma unroll
+                    for (int kk = 0; kk < 7; ++kk) {
+                        const int ow = w - kk + 3;
+                        g7[kk] = (unsigned)ow < (unsigned)a.W ? row[ow] : 0.f;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 7; ++kk) {
+                        const float* k = kw + ((kd * 7 + kh) * 7 + kk) * 2;
+                        if ((unsigned)(w - kk + 3) < (unsigned)a.W) { a0 += g7[kk] * k[0]; a1 += g7[kk] * k[1]; }
+                    }
                 }
             }
         }
-        a.dsp[pos * 2] = a0; a.dsp[pos * 2 + 1] = a1;
+        a0 += __shfl_xor(a0, 1); a0 += __shfl_xor(a0, 2); a0 += __shfl_xor(a0, 4);
+        a1 += __shfl_xor(a1, 1); a1 += __shfl_xor(a1, 2); a1 += __shfl_xor(a1, 4);
+        if (pos < M && kd == 0) { a.dsp[pos * 2] = a0; a.dsp[pos * 2 + 1] = a1; }
     }
 }
 
@@ -222,13 +259,20 @@ __global__ __launch_bounds__(384) void bwd_k7_kernel(CbamArgs a) {
         }
         __syncthreads();
         if (tap < 343) {
-            for (int i = 0; i < 64; ++i) {
-                const int n = pn[i];
-                const int id = pd[i] + kd, ih = ph[i] + kh, iw = pw[i] + kk;
-                if (n >= 0 && (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
-                    const float* sp = a.sp + ((((long long)n * a.D + id) * a.H + ih) * a.W + iw) * 2;
-                    a0 += pg[i] * sp[0]; a1 += pg[i] * sp[1];
+            for (int i0 = 0; i0 < 64; i0 += 8) {       // eight positions' loads in flight; summed in position order
+                float2 v8[8];
+                bool ok[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = i0 + q, n = pn[i];
+                    const int id = pd[i] + kd, ih = ph[i] + kh, iw = pw[i] + kk;
+                    ok[q] = n >= 0 && (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                    v8[q] = ok[q] ? *reinterpret_cast<const float2*>(a.sp + ((((long long)n * a.D + id) * a.H + ih) * a.W + iw) * 2)
+                                  : make_float2(0.f, 0.f);
                 }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (ok[q]) { a0 += pg[i0 + q] * v8[q].x; a1 += pg[i0 + q] * v8[q].y; }
             }
         }
     }
@@ -238,8 +282,15 @@ __global__ __launch_bounds__(384) void bwd_k7_kernel(CbamArgs a) {
     if (!p3d_last_block_wt(a.k7counter, gridDim.x, &last_flag)) return;
     if (tap < 343) {
         float t0 = 0.f, t1 = 0.f;
-#pragma unroll 4
-        for (unsigned b = 0; b < gridDim.x; ++b) { t0 += a.k7part[((size_t)b * 343 + tap) * 2]; t1 += a.k7part[((size_t)b * 343 + tap) * 2 + 1]; }
+        unsigned b = 0;
+        for (; b + 7 < gridDim.x; b += 8) {            // block order, eight partials in flight
+            float2 v8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v8[q] = *reinterpret_cast<const float2*>(a.k7part + ((size_t)(b + q) * 343 + tap) * 2);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { t0 += v8[q].x; t1 += v8[q].y; }
+        }
+        for (; b < gridDim.x; ++b) { t0 += a.k7part[((size_t)b * 343 + tap) * 2]; t1 += a.k7part[((size_t)b * 343 + tap) * 2 + 1]; }
         a.dk7[tap * 2] += t0; a.dk7[tap * 2 + 1] += t1;
     }
 }
@@ -309,6 +360,7 @@ __global__ __launch_bounds__(256) void bwd_mlp1_kernel(CbamArgs a) {
     const int n = blockIdx.y, j0 = blockIdx.x * 8;
     for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
         float s = 0.f;
+#pragma unroll 8
         for (int ch = 0; ch < a.chunks; ++ch) s += a.dcs_part[((long long)n * a.chunks + ch) * a.C + c];
         const float cs = a.cs[(long long)n * a.C + c];
         dO[c] = s * cs * (1.f - cs);
@@ -317,8 +369,10 @@ __global__ __launch_bounds__(256) void bwd_mlp1_kernel(CbamArgs a) {
     __syncthreads();
     const int sl = threadIdx.x & 31, j = j0 + (threadIdx.x >> 5);
     float s = 0.f;
-    if (j < a.Ch)
+    if (j < a.Ch) {
+#pragma unroll 8
         for (int c = sl; c < a.C; c += 32) s += a.k1[(long long)j * a.C + c] * dO[c];
+    }
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (sl == 0 && j < a.Ch) {
@@ -338,10 +392,27 @@ __global__ __launch_bounds__(256) void bwd_mlp2a_kernel(CbamArgs a) {
         const float* dh = a.dh + (long long)n * 2 * a.Ch;
         const float* w = a.k0 + (long long)c * a.Ch;
         float da = 0.f, dm = 0.f;
-        for (int j = 0; j < a.Ch; ++j) { da += w[j] * dh[j]; dm += w[j] * dh[a.Ch + j]; }
+        // (the k0 row of a thread is contiguous: 16-byte loads, eight in flight; same order of the sums as the scalar loop)
+        int j = 0;
+        if ((a.Ch & 3) == 0)
+            for (; j + 31 < a.Ch; j += 32) {
+                float4 wv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) wv[q] = *reinterpret_cast<const float4*>(w + j + 4 * q);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int b = j + 4 * q;
+                    da += wv[q].x * dh[b]; dm += wv[q].x * dh[a.Ch + b];
+                    da += wv[q].y * dh[b + 1]; dm += wv[q].y * dh[a.Ch + b + 1];
+                    da += wv[q].z * dh[b + 2]; dm += wv[q].z * dh[a.Ch + b + 2];
+                    da += wv[q].w * dh[b + 3]; dm += wv[q].w * dh[a.Ch + b + 3];
+                }
+            }
+        for (; j < a.Ch; ++j) { da += w[j] * dh[j]; dm += w[j] * dh[a.Ch + j]; }
         a.davg[i] = da; a.dmx[i] = dm;
         if (n == 0) {
             float s = 0.f;
+#pragma unroll 8
             for (int m = 0; m < a.N; ++m) s += a.dO[(long long)m * a.C + c];
             a.db1[c] += 2.f * s;
         }
@@ -401,7 +472,7 @@ hipError_t p3d_cbam_forward(const CbamArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(chan_hidden_kernel, dim3((a.Ch + 7) / 8, a.N), dim3(256), (2 * a.C + 512) * sizeof(float), s, a);
     hipLaunchKernelGGL(chan_out_kernel, dim3((a.C + 255) / 256, a.N), dim3(256), a.Ch * sizeof(float), s, a);
     hipLaunchKernelGGL(spat_pool_kernel, dim3(capped((M + 3) / 4, 8192)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(spat_conv_kernel, dim3(capped((M + 255) / 256, 4096)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(spat_conv_kernel, dim3(capped((M + 31) / 32, 8192)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -409,7 +480,7 @@ hipError_t p3d_cbam_backward(const CbamArgs& a, hipStream_t s) {
     if ((a.C & 3) || a.C > 1024) return hipErrorInvalidValue;
     const long long M = (long long)a.N * a.D * a.H * a.W;
     hipLaunchKernelGGL(bwd_dpre_kernel, dim3(capped((M + 3) / 4, 8192)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(bwd_spat_conv_kernel, dim3(capped((M + 255) / 256, 4096)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bwd_spat_conv_kernel, dim3(capped((M + 31) / 32, 8192)), dim3(256), 0, s, a);
     {
         const unsigned g7 = capped((M + 63) / 64, 256);      // the last arriver folds g7 partials: keep that tail short
         CbamArgs a7 = a;
