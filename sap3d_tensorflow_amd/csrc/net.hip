@@ -2268,6 +2268,30 @@ struct p3d_handle {
     // with_adam: the optimiser step is part of the call and split in two -- every variable but the first op's is updated while
     // that op's filter gradient (the stem's: the last launch of the pass, alone on the side stream) is still running, the
     // first op's own variables after it.  Returns whether Adam ran (false: the caller launches run_adam).
+    // Gradient buffer (248 MB), gradient arena of the activations and the double-precision reduction arena start a backward pass
+    // at zero.  A train step knows that a backward pass follows its forward pass: it zeroes them on the side stream while the
+    // forward runs (the previous step's optimiser has read the gradients: the side stream is joined before it) instead of
+    // ~0.1 ms of fills at the head of the backward on the main stream.
+    bool zeroed_early = false;
+    hipEvent_t ev_zeroed = nullptr, ev_zero_fork = nullptr;
+    void zero_backward_arenas(hipStream_t st, bool with_zb) {
+        // (zb holds whatever buffers the backward ops zero-fill before adding into them; it is planned from a dry run and may
+        //  name a buffer the forward pass also touches, so it is never zeroed early)
+        if (with_zb && zb_bytes) HIPCHECK(hipMemsetAsync(zb, 0, zb_bytes, st));
+        HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), st));
+        if (red_count) HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), st));
+    }
+    void zero_early(const Ctx& c) {      // call right before run_forward of a train step (not while capturing, not when profiling)
+        if (runtime_env().no_side_stream || !side_stream || c.prof || c.dry) return;
+        if (!ev_zeroed) HIPCHECK(hipEventCreateWithFlags(&ev_zeroed, local_event_flags()));
+        // after everything the main stream has queued so far (the previous step's optimiser and whoever read the gradients)
+        if (!ev_zero_fork) HIPCHECK(hipEventCreateWithFlags(&ev_zero_fork, local_event_flags()));
+        HIPCHECK(hipEventRecord(ev_zero_fork, c.s));
+        HIPCHECK(hipStreamWaitEvent(side_stream, ev_zero_fork, 0));
+        zero_backward_arenas(side_stream, false);
+        HIPCHECK(hipEventRecord(ev_zeroed, side_stream));
+        zeroed_early = true;
+    }
     bool run_backward(const Ctx& c0, bool allreduce, bool with_adam = false) {
         Ctx c = c0; c.z0 = zb; c.z1 = zb + zb_bytes;
         c.fuse = last_forward_fused && !c.dry;       // the backward follows the forward that produced the activations
@@ -2275,9 +2299,13 @@ struct p3d_handle {
         bool adam_done = false;
         const bool no_side = runtime_env().no_side_stream;
         c.side = (c.prof || no_side) ? nullptr : side_stream;      // per-launch profiling keeps one stream
-        if (zb_bytes) HIPCHECK(hipMemsetAsync(zb, 0, zb_bytes, c.s));
-        HIPCHECK(hipMemsetAsync(flat_g, 0, (size_t)n_train * sizeof(float), c.s));
-        if (red_count) HIPCHECK(hipMemsetAsync(red_arena, 0, (size_t)red_count * sizeof(double), c.s));
+        if (zeroed_early) {          // the train step zeroed the backward's arenas on the side stream, beside its forward pass
+            zeroed_early = false;
+            HIPCHECK(hipStreamWaitEvent(c.s, ev_zeroed, 0));
+            if (zb_bytes) HIPCHECK(hipMemsetAsync(zb, 0, zb_bytes, c.s));
+        } else {
+            zero_backward_arenas(c.s, true);
+        }
         int64_t hi = n_train;                        // grads in [hi, n_train) are already handed to the comm stream
         size_t own_pos = own_sorted.size();
         wq.clear(); wq_flushes = 0;
@@ -2463,6 +2491,7 @@ struct p3d_handle {
     void train_step_device(float drop, uint64_t seed) {
         if (!graphs_enabled()) {
             Ctx c; c.training = true; c.drop = drop; c.seed = seed; c.update_moving = true; c.s = stream;
+            zero_early(c);
             run_forward(c); run_loss(c);
             if (!run_backward(c, true, true)) run_adam(c);
             return;
@@ -2510,6 +2539,8 @@ struct p3d_handle {
         if (ev_comm_done) hipEventDestroy(ev_comm_done);
         for (hipEvent_t e : fork_events) hipEventDestroy(e);
         for (hipEvent_t e : wq_events) hipEventDestroy(e);
+        if (ev_zeroed) hipEventDestroy(ev_zeroed);
+        if (ev_zero_fork) hipEventDestroy(ev_zero_fork);
         if (ev_side_done) hipEventDestroy(ev_side_done);
         if (ev_side_early) hipEventDestroy(ev_side_early);
         if (ev_comm_early) hipEventDestroy(ev_comm_early);
