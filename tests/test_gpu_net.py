@@ -149,8 +149,8 @@ def test_dropout_statistics():
     s.forward(x, 0.0, False)
     base_eval = s.activation('deconv3_re')
     s.forward(x, 0.5, False)
-    # split-K partial sums are combined with fp32 atomics: run-to-run identical only to ~1e-6
-    assert np.abs(s.activation('deconv3_re') - base_eval).max() < 1e-4
+    # inference ignores the dropout rate, and the path is bit-reproducible (no floating-point atomics since round 2)
+    assert np.array_equal(s.activation('deconv3_re'), base_eval)
     s.forward(x, 0.0, True)
     base = s.activation('deconv3_re')
     s.forward(x, 0.5, True, seed=11)
@@ -628,9 +628,8 @@ def test_eager_graph_function_mirrors():
     try:
         a = hp.p3d_unet(x, 0.0, batch_size=1, training=False)
         s = hp.session_for("unet", x.shape)
-        assert a.shape == (1, 16, 32, 32, 1) and np.abs(a - s.forward(x, 0.0, False)).max() < 2e-2
-        # (not bitwise: at 32x32 the reference architecture's stage 3 normalises over 1x2x2 = 4 positions per channel, and
-        #  36 such blocks amplify the split-K atomics' 1e-7 reordering noise to ~3e-3 on the maps)
+        # the eager mirror IS the cached session's forward, and the path is bit-reproducible: the same bits
+        assert a.shape == (1, 16, 32, 32, 1) and np.array_equal(a, s.forward(x, 0.0, False))
         assert 0.0 < a.min() and a.max() < 1.0
         assert 'firstconv1' in s.save()
         assert hp.p3d_concat(x, 0.0, 1, False).shape == (1, 16, 32, 32, 1)
