@@ -700,7 +700,11 @@ WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
     const bool forced = g_force_tm != 0;
     // (from 2048 positions: deconv2's filter gradient at 8 clips of 16x112x112, 6272 positions x 18 taps, 493 -> 359 us; deconv1's
     // at 32x224x224, 3136 positions, 473 -> 340 us)
-    const bool busy = other_tiles == 0 && M >= 2048 && a.Nc >= 128 && !wtune().no_rect && !forced;
+    // Round 3, per-launch sweeps (tools/op_times.py --wgrad-tile): launches with 256 or more 64x64 tiles take part whatever their
+    // position count (deconv1 at 8 clips of 16x112x112, 392 positions: 89 -> 69 us).  128x128 tiles win ALONE wherever there are
+    // 128 or more of them (the GN head's 1792 -> 1024 conv 23.2 -> 21.9 ms, the unet++ decoder convs 6-11 %) and lose in the
+    // step, again (GN net 93.1 -> 93.7 ms, unet++ 56.5 -> 56.7): 64x128 stays.
+    const bool busy = other_tiles == 0 && (M >= 2048 || tiles_of(a, 64, 64) >= 256) && a.Nc >= 128 && !wtune().no_rect && !forced;
     if (busy) return best_for(64, 128);
     WPlan best = best_for(64, 64);
     if (other_tiles == 0) {
