@@ -142,6 +142,39 @@ def test_bottlenecks_at_batch8_against_the_oracle(ref_params, block_id):
     assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)
 
 
+@pytest.mark.parametrize("block_id", [1, 2, 4])
+def test_gn_cbam_bottlenecks_at_batch8_against_the_oracle(block_id):
+    """configs[3]'s per-GPU share (8 clips of 16x112x112) of the GroupNorm + CBAM graph: non-first bottlenecks of stages 1 and 2
+    (gn/p3d_gn.py:127-179, identity residual, CBAM on it) through p3d_block_forward against the oracle -- the large-tensor GroupNorm
+    passes with their write-through hand-overs, CBAM's pooling / MLP / 7x7x7 kernels at 50176 and 6272 positions."""
+    from oracle import nn, p3d_gn
+    from sap3d_tensorflow_amd import P3DSession
+    cfg = p3d.REFERENCE_CFG
+    p64 = p3d_gn.init_params(1, cfg, dtype=np.float64)
+    rng = np.random.default_rng(7)
+    for k, v in p64.items():
+        if k.endswith('gamma'):
+            v[:] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith('beta'):
+            v[:] = rng.uniform(-0.3, 0.3, v.shape)
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    s = P3DSession('gn_p3d', batch=8)
+    s.load(p32)
+    ishape, _ = s.block_shapes(block_id)
+    x = np.random.default_rng(2).standard_normal(ishape).astype(np.float32)
+    got = s.block_forward(block_id, x)
+    s.close()
+    names = list(p64)
+    k0 = names.index('conv3_%d_1' % block_id)
+    gn = next(n for n in names[k0:] if n.startswith('group_norm') and n.endswith('/gamma')).split('/')[0]
+    g = p3d.Graph(p64, dtype=np.float64, create=False)
+    g._uniq['group_norm'] = int(gn.split('_')[-1])
+    planes = (cfg.base, 2 * cfg.base)[0 if block_id < 3 else 1]
+    want = p3d_gn.Bottleneck(g, nn.Var(x.astype(np.float64)), 4 * planes, planes, n_s=block_id).infer().data
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)
+
+
 @pytest.mark.parametrize("structure,shape,step,tol,first_group", [
     ("unet", (8, 16, 112, 112), 2e-5, 8e-2, 0),       # BASELINE.json configs[2]: batch 8, 16x112x112
     ("unet", (1, 32, 224, 224), 2e-5, 8e-2, 0),       # the clip shape of configs[4] (32 frames of 224x224), one clip
