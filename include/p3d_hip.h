@@ -139,6 +139,10 @@ int p3d_get_activation(p3d_handle* h, const char* name, float* host, int64_t cou
  *      everywhere in the backbone. */
 int p3d_block_info(p3d_handle* h, int block_id, int64_t in_shape[5], int64_t out_shape[5]);
 int p3d_block_forward(p3d_handle* h, int block_id, const float* in, int64_t in_count, float* out, int64_t out_count);
+/* The same bottleneck, forward then backward: `dout` is the gradient of its output, `din` receives the gradient of its input; the
+ * gradients of the block's own variables are read with p3d_get_grad afterwards (every other variable's gradient reads 0).
+ * Parity hook for gradients at sizes where the whole graph is out of the oracle's reach. */
+int p3d_block_backward(p3d_handle* h, int block_id, const float* in, int64_t in_count, const float* dout, int64_t out_count, float* din);
 
 /* ---- device-resident stepping for measurement: inputs already in HBM (bench.py).
  *      p3d_device_inputs returns the handle's own x / y staging buffers (device pointers,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "p3d_predict_windows": (C.c_int, [C.c_void_p, _fp, _fp]),
     "p3d_block_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "p3d_block_forward": (C.c_int, [C.c_void_p, C.c_int, _fp, C.c_int64, _fp, C.c_int64]),
+    "p3d_block_backward": (C.c_int, [C.c_void_p, C.c_int, _fp, C.c_int64, _fp, C.c_int64, _fp]),
     "p3d_set_pointwise_fp16": (C.c_int, [C.c_void_p, C.c_int]),
     "p3d_set_bn_fusion": (C.c_int, [C.c_void_p, C.c_int]),
     "p3d_set_attention_mode": (C.c_int, [C.c_void_p, C.c_int]),

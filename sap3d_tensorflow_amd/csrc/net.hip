@@ -2934,6 +2934,36 @@ int p3d_block_forward(p3d_handle* h, int block_id, const float* in, int64_t in_c
     API_END
 }
 
+int p3d_block_backward(p3d_handle* h, int block_id, const float* in, int64_t in_count, const float* dout, int64_t out_count, float* din) {
+    API_BEGIN
+    if (!h || !in || !dout || !din) throw P3dError("null argument");
+    auto it = h->blocks.find(block_id);
+    if (it == h->blocks.end()) throw P3dError("no bottleneck with id " + std::to_string(block_id));
+    Act* a = it->second.in; Act* b = it->second.out;
+    if (in_count != a->rows() * a->C || out_count != b->rows() * b->C) throw P3dError("block tensor size mismatch");
+    if (!a->g || !b->g) throw P3dError("this bottleneck's input or output carries no gradient");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    HIPCHECK(hipMemcpy2DAsync(a->p, (size_t)a->ld * 4, in, (size_t)a->C * 4, (size_t)a->C * 4, (size_t)a->rows(), hipMemcpyHostToDevice, h->stream));
+    Ctx c; c.training = true; c.s = h->stream; c.fuse = false;
+    h->last_forward_fused = false;
+    if (h->stats_count) HIPCHECK(hipMemsetAsync(h->stats_arena, 0, (size_t)h->stats_count * sizeof(double), c.s));
+    for (size_t i = it->second.op0; i < it->second.op1; ++i) h->ops[i].fwd(c);
+    // the backward walk of run_backward over this block's ops only, on one stream; the block's output gradient is given
+    h->zeroed_early = false;
+    h->zero_backward_arenas(c.s, true);
+    c.z0 = h->zb; c.z1 = h->zb + h->zb_bytes;
+    HIPCHECK(hipMemcpy2DAsync(b->g, (size_t)b->ld * 4, dout, (size_t)b->C * 4, (size_t)b->C * 4, (size_t)b->rows(), hipMemcpyHostToDevice, c.s));
+    h->wq.clear(); h->wq_flushes = 0; h->parked_flops = 0;
+    for (size_t i = it->second.op1; i-- > it->second.op0;) {
+        c.bwd_op = h->ops[i].name.c_str();
+        h->ops[i].bwd(c);
+    }
+    h->flush_wgrads(c);
+    HIPCHECK(hipStreamSynchronize(c.s));
+    HIPCHECK(hipMemcpy2D(din, (size_t)a->C * 4, a->g, (size_t)a->ld * 4, (size_t)a->C * 4, (size_t)a->rows(), hipMemcpyDeviceToHost));
+    API_END
+}
+
 int p3d_profile_step(p3d_handle* h, float dropout_rate, uint64_t seed, p3d_op_time* out, int cap) {
     if (!h) { g_err = "null handle"; return -1; }
     try {

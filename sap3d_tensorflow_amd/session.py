@@ -162,6 +162,18 @@ class P3DSession:
         check(lib().p3d_block_forward(self._h, int(block_id), fptr(a), a.size, fptr(out), out.size))
         return out
 
+    def block_backward(self, block_id, x, dout):
+        """Bottleneck `block_id` in isolation, forward then backward: -> gradient of its input; the block's own variables'
+        gradients are then readable with get_grad."""
+        ishape, oshape = self.block_shapes(block_id)
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        d = np.ascontiguousarray(dout, dtype=np.float32)
+        if a.shape != ishape or d.shape != oshape:
+            raise ValueError("block %d takes %s and returns %s" % (block_id, ishape, oshape))
+        din = np.empty(ishape, np.float32)
+        check(lib().p3d_block_backward(self._h, int(block_id), fptr(a), a.size, fptr(d), d.size, fptr(din)))
+        return din
+
     def set_pointwise_fp16(self, enable=True):
         """BASELINE configs[4]: 1x1x1 convs on the fp16 matrix cores (fp32 accumulate, fp32 storage); fp16-level parity."""
         check(lib().p3d_set_pointwise_fp16(self._h, int(bool(enable))))
