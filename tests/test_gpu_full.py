@@ -106,7 +106,7 @@ def test_config2_forward_backward(ref_params):
     s.close()
 
 
-@pytest.mark.parametrize("block_id", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("block_id", [0, 1, 2, 3, 4, 11, 12, 13])
 def test_bottlenecks_at_batch8_against_the_oracle(ref_params, block_id):
     """Single bottlenecks of the reference architecture at the batch of configs[2] (8 clips of 16x112x112: 50176 positions in
     stage 1, 6272 in stage 2) through p3d_block_forward against the oracle's Bottleneck -- the launch shapes the train step uses:
@@ -119,10 +119,10 @@ def test_bottlenecks_at_batch8_against_the_oracle(ref_params, block_id):
     s = P3DSession('unet', batch=8)
     s.load(ref_params)
     b = cfg.base
-    stage = 0 if block_id < 3 else 1
-    first = block_id in (0, 3)
-    planes = (b, 2 * b)[stage]
-    inplanes = b if block_id == 0 else (4 * b if first else 4 * planes)
+    stage = 0 if block_id < 3 else (1 if block_id < 11 else 2)          # blocks (3, 8, 36): stage 3 = ids 11..46 (784 positions)
+    first = block_id in (0, 3, 11)
+    planes = (b, 2 * b, 4 * b)[stage]
+    inplanes = b if block_id == 0 else (4 * (b, 2 * b, 4 * b)[stage - 1] if first else 4 * planes)
     ishape, _ = s.block_shapes(block_id)
     assert ishape[0] == 8 and ishape[4] == inplanes
     x = np.random.default_rng(2).standard_normal(ishape).astype(np.float32)
@@ -142,7 +142,7 @@ def test_bottlenecks_at_batch8_against_the_oracle(ref_params, block_id):
     assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)
 
 
-@pytest.mark.parametrize("block_id", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("block_id", [0, 1, 2, 3, 4, 11, 12, 13])
 def test_bottleneck_gradients_at_batch8_against_the_oracle(ref_params, block_id):
     """The backward pass of single bottlenecks at the batch of configs[2] (p3d_block_backward): gradient of the block's input and
     of each of its variables against the float64 oracle's tape -- input gradients over several rounds with K-sliced tails and
@@ -161,10 +161,10 @@ def test_bottleneck_gradients_at_batch8_against_the_oracle(ref_params, block_id)
     s = P3DSession('unet', batch=8)
     s.load({k: v.astype(np.float32) for k, v in p64.items()})
     b = cfg.base
-    stage = 0 if block_id < 3 else 1
-    first = block_id in (0, 3)
-    planes = (b, 2 * b)[stage]
-    inplanes = b if block_id == 0 else (4 * b if first else 4 * planes)
+    stage = 0 if block_id < 3 else (1 if block_id < 11 else 2)          # blocks (3, 8, 36): stage 3 = ids 11..46 (784 positions)
+    first = block_id in (0, 3, 11)
+    planes = (b, 2 * b, 4 * b)[stage]
+    inplanes = b if block_id == 0 else (4 * (b, 2 * b, 4 * b)[stage - 1] if first else 4 * planes)
     ishape, oshape = s.block_shapes(block_id)
     x = rng.standard_normal(ishape).astype(np.float32)
     dy = rng.standard_normal(oshape).astype(np.float32)
