@@ -2,7 +2,7 @@
 """Headline benchmark: clips/s of the P3D (p3d_unet) train step -- forward + Smooth-L1 loss +
 backward + Adam -- on synthetic 16x112x112x3 clips, batch 8 per GPU, fp32, on N MI355X.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts the N ranks itself, as a child process)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One rank per GPU; each rank owns its shard of clips (weak scaling) and the only exchange is the
@@ -147,6 +147,22 @@ def cpu_baseline():
     return best
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a child process on a free
+    local port, pass its output through (rank 0 prints the ONE JSON line) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +184,11 @@ def main():
     ap.add_argument("--dump-launches", default=None, help="write every launch record of the profiled step to this CSV")
     ap.add_argument("--per-layer", default=None, help="write the per-layer roofline table of the profiled step to this CSV")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: this process has not touched the GPU yet; it only starts the N ranks as a CHILD
+        # (never an exec) and relays rank 0's JSON line and the child's exit code
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from sap3d_tensorflow_amd.dp import Plane
     plane = Plane()

@@ -94,10 +94,33 @@ struct BnGate {            // epilogue of an input-gradient launch: g = (scale*y
     float* out; int ldo;                         // gated gradient
     float* part;                                 // [m tiles][Nc][2]  (sum g, sum g*xhat) per output-tile row, plain stores
 };
+// ---- BatchNorm in the PRODUCING conv's epilogue (round 4; small tensors: every output tile of the launch is resident at once).
+// The block that holds a finished output tile (the last arriver of its K-slices) publishes the tile's per-channel (sum, sumsq)
+// as 8-byte {value, epoch} granules with ONE write-through store each, sweeps the granules of the other row tiles of its
+// column range (agent-scope loads, no flag, no fence: the epoch tag says "this launch's value"), folds them in tile order in
+// double -- every block of a column range computes the same bits -- and applies scale / shift (+ ReLU, + residual) to the
+// tile it still holds in LDS: y (raw) and z (normalised) leave in one launch, the BatchNorm pass of its own is gone.
+// Waiting blocks hold their CU slot, so the launcher only takes this path when tiles <= P3D_EB_MAX_TILES (every tile's
+// last arriver can be resident beside the blocks still to run); spins are bounded by wall time and report through `err`.
+#define P3D_EB_MAX_MTILES 16
+#define P3D_EB_MAX_TILES 224
+struct BnEpi {
+    int mode;                    // 0: off.  1: z = relu(bn(y))   2: z = relu(bn(y) + r)   3: z = r + relu(bn(y))   (bn_apply modes 0, 1, 4)
+    float* z; int ldz;
+    const float* r; int ldr;     // residual / skip operand on the output lattice
+    const float* gamma; const float* beta;
+    float* scale; float* shift; float* mean; float* invstd;     // published by the row-tile-0 block of every column range
+    float* moving_mean; float* moving_var; int update_moving;
+    unsigned long long* xch;     // [m tiles][Nc][2] granules (filled by the launcher)
+    unsigned epoch;              // tag of this launch (filled by the launcher)
+    unsigned* err;               // device word: set when a sweep gave up (filled by the launcher)
+    double inv_m; float eps;
+};
 enum { P3D_AT_NONE = 0, P3D_AT_RELU1 = 1, P3D_AT_RELU2 = 2, P3D_AT_GRAD = 3 };
 //  RELU1: a = relu(s1*x + t1)                           RELU2: a = relu(s1*x + t1) + relu(s2*x2 + t2)   (ST_B / ST_C sums)
 //  GRAD : a = k1*x + k2*x2 + k3   (x = gated gradient, x2 = BN input); padded taps stay 0
 
+struct P3dIgemmPlan;
 // Implicit-GEMM convolution launch:  Y[m, n] (+)= sum_taps sum_k A[m+tap, k] * B_tap[k, n] (+ bias[n])
 struct IgemmArgs {
     const float* x;       // gathered operand (already offset to its channel slice)
@@ -137,6 +160,7 @@ struct IgemmArgs {
     // (after bias / accumulate) goes raw to y when raw_store, and gated to gate[q].out; ngate = 0: plain store to y
     int ngate, raw_store;
     BnGate gate[2];
+    BnEpi eb;             // BatchNorm in this launch's own epilogue (single-class launches of 64x64 tiles)
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
 };
@@ -178,6 +202,10 @@ inline int p3d_igemm2_mtiles(const IgemmArgs& a, const P3dIgemmPlan& pl) {
 // Per-stream scratch for K-sliced launches (partial tiles + arrival counters).  Launches on one stream run in order, so
 // they share it; the buffers only grow, and an outgrown buffer stays allocated (captured graphs may still name it).
 hipError_t p3d_stream_scratch(hipStream_t s, size_t slab_floats, size_t counters, float** slab, unsigned** cnt);
+// granule scratch of the epilogue BatchNorm for the next launch on stream s (+ that launch's epoch tag and the give-up word)
+hipError_t p3d_stream_xch(hipStream_t s, size_t granules, unsigned long long** xch, unsigned* epoch, unsigned** err);
+bool p3d_igemm2_eb_ok(const IgemmArgs& a, const struct P3dIgemmPlan& pl);      // may this launch carry a.eb?  (tile shape, tile counts)
+long long p3d_eb_timeouts();                 // sweeps that gave up so far (synchronises; must be 0), -1 on a HIP error
 long long p3d_scratch_dirty_counters();      // test hook: non-zero arrival counters with nothing in flight (must be 0)
 void p3d_release_scratch();     // frees every scratch buffer (process shutdown; no launch may be in flight)
 

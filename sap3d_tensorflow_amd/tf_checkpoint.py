@@ -482,13 +482,27 @@ def write_checkpoint(prefix, variables, block_bytes=262144):
         out.extend(_with_trailer(blk))
         cur = []
 
+    # BlockBuilder::CurrentSizeEstimate() = entry bytes + 4 per restart point + 4 (the restart count), kept as a running sum
+    # (re-encoding the open block per entry made the index build quadratic in the number of variables)
+    est, last = 8, b""
     for k, v in entries:
         if pending:
             index.append((_shortest_separator(pending[0], k), pending[1]))
             pending = None
+        shared = 0
+        if len(cur) % 16 == 0:
+            if cur:
+                est += 4                   # a new restart point (the first one is in the 8 above)
+        else:
+            m = min(len(last), len(k))
+            while shared < m and last[shared] == k[shared]:
+                shared += 1
+        est += len(_varint(shared)) + len(_varint(len(k) - shared)) + len(_varint(len(v))) + len(k) - shared + len(v)
         cur.append((k, v))
-        if len(_block(cur)) >= block_bytes:        # BlockBuilder::CurrentSizeEstimate() is exact for an uncompressed block
+        last = k
+        if est >= block_bytes:
             flush()
+            est, last = 8, b""
     if cur:
         flush()
     if pending:
@@ -519,8 +533,9 @@ def update_checkpoint_state(directory, prefix, keep=10):
         for p in paths:
             f.write('all_model_checkpoint_paths: "%s"\n' % p)
     import glob
-    for p in dropped:                                   # Saver deletes what falls out of the window: every file of the prefix
-        for fn in glob.glob(glob.escape(os.path.join(directory, p)) + ".*"):      # .index, every .data-?????-of-?????, a TF-written .meta
+    for p in dropped:                                   # Saver deletes what falls out of the window: exactly the files of that prefix
+        base = os.path.join(directory, p)               # (not `<prefix>.*`: `model.best.index` or a `<prefix>.metrics.json` are not ours)
+        for fn in [base + ".index", base + ".meta"] + glob.glob(glob.escape(base) + ".data-[0-9][0-9][0-9][0-9][0-9]-of-[0-9][0-9][0-9][0-9][0-9]"):
             try:
                 os.remove(fn)
             except OSError:

@@ -72,3 +72,36 @@ def test_two_rank_control_plane_and_gradient_sum():
     for n in want:
         assert np.allclose(g0[n], want[n], rtol=1e-12, atol=1e-12), n
         assert np.array_equal(g0[n], g1[n]), n
+
+
+def test_bare_bench_command_starts_the_ranks_as_a_child(monkeypatch):
+    """`python bench.py --gpus N` with no torch.distributed.run environment must start the ranks itself, as a CHILD process
+    (a process that has touched the GPU may never exec another program), pass the arguments through unchanged and hand back the
+    child's exit code.  No GPU is needed to check the command it builds."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    try:
+        bench.main()
+        raise AssertionError("bench.main() must exit with the child's code")
+    except SystemExit as e:
+        assert e.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "2"]
+    assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")

@@ -95,17 +95,18 @@ def test_single_rank_allreduce_is_identity(structure, bucket_mb, monkeypatch):
 
 
 def test_bench_launch_path_with_two_ranks_on_one_gpu(tmp_path):
-    """The driver's multi-GPU command line (torch.distributed.run, one rank per GPU, rank 0 prints ONE JSON line), rehearsed on
+    """The driver's multi-GPU command line in its BARE form (`python bench.py --gpus 2 ...`, no torch.distributed.run around
+    it: bench.py starts the ranks itself as a child process and relays rank 0's ONE JSON line and the exit code), rehearsed on
     a one-GPU box: P3D_BENCH_REHEARSAL=1 puts both ranks on device 0 and builds no RCCL communicator (RCCL refuses two ranks
-    on one device), so this covers the rendezvous, the barriers, the max-over-ranks timing and the output contract -- not the
-    all-reduce."""
+    on one device), so this covers the launch, the rendezvous, the barriers, the max-over-ranks timing and the output
+    contract -- not the all-reduce."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, P3D_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["P3D_BENCH_REHEARSAL"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
