@@ -32,7 +32,9 @@
 #error "the K-slice exchange (write-through slab stores + relaxed ticket + one-lane acquire) is written for gfx942 / gfx950 cache semantics"
 #endif
 #include "p3d_kernels.h"
+#include "igemm_epilogue.h"
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -91,17 +93,6 @@ struct BLoad {
     const float* w;          // weight tensor of this launch / class
 };
 
-// The per-class part of a launch as the kernel body sees it: from the kernel arguments themselves (one class) or from the
-// class table of a grouped launch
-struct Geo {
-    int Gd, Gh, Gw;
-    P3dFastDiv fGd, fGh, fGw;
-    int ood, ooh, oow, stat_base, ntaps;
-    const P3dTap* taps;
-    const float* w; const float* bias; float* y; float* statpart;      // a grouped launch may also carry sibling convs (ST_B)
-    int nsplit; float* slab; unsigned* cnt;                             // K-slices of this launch / class and their scratch
-};
-
 template <int BM, bool TWO>
 __device__ __forceinline__ void a_init(const IgemmArgs& p, const Geo& geo, ALoad<BM / 32, TWO>& st, unsigned m0, unsigned M, int wave, int lane,
                                        int s_begin, int kchunks) {
@@ -150,8 +141,8 @@ __device__ __forceinline__ void b_init(const IgemmArgs& p, const float* w, BLoad
 }
 
 template <int LA, bool TWO>
-__device__ __forceinline__ void a_set_tap(const IgemmArgs& p, const P3dTap* taps, ALoad<LA, TWO>& st) {
-    const P3dTap tap = taps[st.t];
+__device__ __forceinline__ void a_set_tap(const IgemmArgs& p, P3dKTap* taps, ALoad<LA, TWO>& st) {
+    const P3dTap tap = p3d_ktap(taps, st.t);
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int id = (st.dhw[i] >> 20) + tap.dd, ih = ((st.dhw[i] >> 10) & 1023) + tap.dh, iw = (st.dhw[i] & 1023) + tap.dw;
@@ -168,7 +159,7 @@ __device__ __forceinline__ void a_set_tap(const IgemmArgs& p, const P3dTap* taps
 // __restrict__ so that, inlined next to the fragment reads, hipcc knows the reads cannot alias the DMA
 // targets and does not put s_waitcnt vmcnt(0) in front of them.
 template <int BM>
-__device__ __forceinline__ void issue_a_dma(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ a_dst, ALoad<BM / 32, false>& st, int nsteps,
+__device__ __forceinline__ void issue_a_dma(const IgemmArgs& p, P3dKTap* taps, float* __restrict__ a_dst, ALoad<BM / 32, false>& st, int nsteps,
                                             int kchunks, bool first, int wave, int lane) {
     constexpr int LA = BM / 32;
     const bool live = st.issued < nsteps;
@@ -184,7 +175,7 @@ __device__ __forceinline__ void issue_a_dma(const IgemmArgs& p, const P3dTap* ta
     if (++st.kc == kchunks) { st.kc = 0; ++st.t; }
 }
 template <int BN, bool WT>
-__device__ __forceinline__ void issue_b_dma(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ b_dst, BLoad<BN / 32>& st, int nsteps, int kchunks,
+__device__ __forceinline__ void issue_b_dma(const IgemmArgs& p, P3dKTap* taps, float* __restrict__ b_dst, BLoad<BN / 32>& st, int nsteps, int kchunks,
                                             int wave, int lane) {
     // (the weight base travels in the loader state: per class in a grouped launch)
     constexpr int LB = BN / 32;
@@ -222,7 +213,7 @@ struct AMeta {
     int k0;                  // channel base of the step (coefficient table offset)
 };
 template <int BM, int AT>
-__device__ __forceinline__ void issue_a_raw(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ raw_dst, float* __restrict__ raw2_dst, AMeta& r,
+__device__ __forceinline__ void issue_a_raw(const IgemmArgs& p, P3dKTap* taps, float* __restrict__ raw_dst, float* __restrict__ raw2_dst, AMeta& r,
                                             ALoad<BM / 32, ATr<AT>::two>& st, int nsteps, int kchunks, bool first, int wave, int lane) {
     constexpr int LA = BM / 32;
     constexpr bool TWO = ATr<AT>::two;
@@ -385,7 +376,7 @@ struct Lds {      // float offsets inside the ring region
 // Branch-free: wait for this step's loads, barrier, read the stage's fragments, first half of the MFMAs, issue step+2,
 // second half.
 template <int BM, int BN, bool WT, bool F16>
-__device__ __forceinline__ void pipe_step(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ a_dst, float* __restrict__ b_dst,
+__device__ __forceinline__ void pipe_step(const IgemmArgs& p, P3dKTap* taps, float* __restrict__ a_dst, float* __restrict__ b_dst,
                                           const float* __restrict__ a_src, const float* __restrict__ b_src,
                                           f32x16 (&acc)[BM / 64][BN / 64], ALoad<BM / 32, false>& sa, BLoad<BN / 32>& sb, int nsteps,
                                           int kchunks, int wave, int lane, int wm, int wn) {
@@ -405,7 +396,7 @@ __device__ __forceinline__ void pipe_step(const IgemmArgs& p, const P3dTap* taps
 // between the MFMA halves the lane transforms the NEXT step's A chunks out of their raw slot, then re-targets that raw slot
 // with the DMA of STAGES steps ahead and issues the B DMA of STAGES - 1 steps ahead.
 template <int BM, int BN, bool WT, bool F16, int AT>
-__device__ __forceinline__ void pipe_step_fused(const IgemmArgs& p, const P3dTap* taps, float* __restrict__ a_next, float* __restrict__ b_dst,
+__device__ __forceinline__ void pipe_step_fused(const IgemmArgs& p, P3dKTap* taps, float* __restrict__ a_next, float* __restrict__ b_dst,
                                                 float* __restrict__ raw, float* __restrict__ raw2,
                                                 const float* __restrict__ a_src, const float* __restrict__ b_src,
                                                 const float* __restrict__ tab, int kp, f32x16 (&acc)[BM / 64][BN / 64],
@@ -429,7 +420,7 @@ __device__ __forceinline__ void pipe_step_fused(const IgemmArgs& p, const P3dTap
 
 template <int BM, int BN, bool WT, bool F16, int K>
 struct StepLoop {
-    static __device__ __forceinline__ void run(const IgemmArgs& p, const P3dTap* taps, float* ring, f32x16 (&acc)[BM / 64][BN / 64],
+    static __device__ __forceinline__ void run(const IgemmArgs& p, P3dKTap* taps, float* ring, f32x16 (&acc)[BM / 64][BN / 64],
                                                ALoad<BM / 32, false>& sa, BLoad<BN / 32>& sb, int base, int nsteps, int kchunks,
                                                int wave, int lane, int wm, int wn) {
         using L = Lds<BM, BN, 0>;
@@ -446,7 +437,7 @@ struct StepLoop {
 // fused: the period of (B slot, A slot, raw slot) is STAGES * (STAGES - 1) steps, all indices compile-time
 template <int BM, int BN, bool WT, bool F16, int AT, int K>
 struct FusedLoop {
-    static __device__ __forceinline__ void run(const IgemmArgs& p, const P3dTap* taps, float* ring, const float* tab, int kp, f32x16 (&acc)[BM / 64][BN / 64],
+    static __device__ __forceinline__ void run(const IgemmArgs& p, P3dKTap* taps, float* ring, const float* tab, int kp, f32x16 (&acc)[BM / 64][BN / 64],
                                                AMeta (&meta)[Ring<BM, BN>::stages - 1], ALoad<BM / 32, ATr<AT>::two>& sa,
                                                BLoad<BN / 32>& sb, int base, int nsteps, int kchunks, int wave, int lane, int wm, int wn) {
         using L = Lds<BM, BN, AT>;
@@ -535,10 +526,6 @@ __device__ __forceinline__ void build_table(const IgemmArgs& p, float* tab, int 
     }
 }
 
-__device__ __forceinline__ float4 shfl_xor4(float4 v, int o) {
-    return make_float4(__shfl_xor(v.x, o), __shfl_xor(v.y, o), __shfl_xor(v.z, o), __shfl_xor(v.w, o));
-}
-
 template <int BM, int BN, bool WT, bool F16, int AT>
 __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, const int tile_id, const int slice) {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -561,27 +548,32 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
     const long long M = (long long)p.N * geo.Gd * geo.Gh * geo.Gw;
     const int NT = (p.Nc + BN - 1) / BN;
     const int nsplit = geo.nsplit;
-    const P3dTap* taps = geo.taps;
+    P3dKTap* taps = geo.taps;
     const int nt = tile_id % NT;
     const int mt = tile_id / NT;
     const long long m0 = (long long)mt * BM;
     const int n0 = nt * BN;
     const int kchunks = (p.K + BK - 1) / BK;
     const int kp = kchunks * BK;
+    const float4 bias4 = igemm_bias_prefetch<BN>(geo.bias, n0, p.Nc);      // for the epilogue; in flight behind the whole main loop
 
     const unsigned Mu = (unsigned)M, m0u = (unsigned)m0;      // launcher guarantees M < 2^31
-    for (int r = tid; r < BM; r += 256) {
-        const unsigned m = m0u + r;
-        int ro = -1;
-        if (m < Mu) {
-            const unsigned t1 = p3d_div(m, geo.fGw), gw = m - t1 * (unsigned)geo.Gw;
-            const unsigned t2 = p3d_div(t1, geo.fGh), gh = t1 - t2 * (unsigned)geo.Gh;
-            const unsigned n = p3d_div(t2, geo.fGd), gd = t2 - n * (unsigned)geo.Gd;
-            const int od = gd * p.osd + geo.ood, oh = gh * p.osh + geo.ooh, ow = gw * p.osw + geo.oow;
-            ro = (((int)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+    // the epilogue's output-row table: written once the first operand loads are in flight (it used to stand between the kernel
+    // entry and them); nobody reads it before the barrier that ends the main loop
+    auto fill_row_table = [&]() {
+        for (int r = tid; r < BM; r += 256) {
+            const unsigned m = m0u + r;
+            int ro = -1;
+            if (m < Mu) {
+                const unsigned t1 = p3d_div(m, geo.fGw), gw = m - t1 * (unsigned)geo.Gw;
+                const unsigned t2 = p3d_div(t1, geo.fGh), gh = t1 - t2 * (unsigned)geo.Gh;
+                const unsigned n = p3d_div(t2, geo.fGd), gd = t2 - n * (unsigned)geo.Gd;
+                const int od = gd * p.osd + geo.ood, oh = gh * p.osh + geo.ooh, ow = gw * p.osw + geo.oow;
+                ro = (((int)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+            }
+            rowIdx[r] = ro;
         }
-        rowIdx[r] = ro;
-    }
+    };
     // ---- this block's slice of the (tap, k-chunk) steps --------------------------------------------
     const int total_steps = geo.ntaps * kchunks;
     const int per = (total_steps + nsplit - 1) / nsplit;
@@ -609,6 +601,7 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
             issue_a_dma<BM>(p, taps, ring + k * L::A_STAGE, sa, nsteps, kchunks, k == 0, wave, lane);
             issue_b_dma<BN, WT>(p, taps, ring + L::B_OFF + k * L::B_STAGE, sb, nsteps, kchunks, wave, lane);
         }
+        fill_row_table();
         for (int base = 0; base < nsteps; base += STAGES)
             StepLoop<BM, BN, WT, F16, 0>::run(p, taps, ring, acc, sa, sb, base, nsteps, kchunks, wave, lane, wm, wn);
     } else {
@@ -618,6 +611,7 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
         AMeta meta[STAGES - 1];
         float* raw = ring + L::RAW_OFF;
         float* raw2 = ring + L::RAW2_OFF;
+        fill_row_table();
         issue_a_raw<BM, AT>(p, taps, raw, raw2, meta[0], sa, nsteps, kchunks, true, wave, lane);
         if constexpr (STAGES == 3) {
             issue_a_raw<BM, AT>(p, taps, raw + L::A_STAGE, raw2 + L::A_STAGE, meta[1], sa, nsteps, kchunks, false, wave, lane);
@@ -732,193 +726,7 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& p, const Geo& geo, 
         __syncthreads();
     }
 
-    if (p.ngate > 0) {
-        // -- gated output (input gradient through fused BatchNorm + ReLU pairs): every lane owns ONE float4 column group
-        //    (256 % F4R == 0) and walks rows, so the per-channel (sum g, sum g*xhat) accumulate in registers; lanes of a
-        //    wave that share the column group are folded by shuffles, the four waves through LDS, all in a fixed order.
-        const int c4 = (tid % F4R) * 4, col = n0 + c4;
-        const bool cok = col < p.Nc;
-        float4 sc[2], sh[2], mu[2], iv[2], s[2], sx[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            s[q] = make_float4(0.f, 0.f, 0.f, 0.f); sx[q] = s[q]; sc[q] = s[q]; sh[q] = s[q]; mu[q] = s[q]; iv[q] = s[q];
-            if (q < p.ngate && cok) {
-                sc[q] = *reinterpret_cast<const float4*>(p.gate[q].scale + col); sh[q] = *reinterpret_cast<const float4*>(p.gate[q].shift + col);
-                mu[q] = *reinterpret_cast<const float4*>(p.gate[q].mean + col); iv[q] = *reinterpret_cast<const float4*>(p.gate[q].invstd + col);
-            }
-        }
-        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (geo.bias && cok) bias4 = *reinterpret_cast<const float4*>(geo.bias + col);
-#pragma unroll 2
-        for (int r = tid / F4R; r < BM; r += 256 / F4R) {
-            const int ro = rowIdx[r];
-            if (ro < 0 || !cok) continue;
-            float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
-            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-            if (p.accum) { const float4 o = *reinterpret_cast<const float4*>(geo.y + (long long)ro * p.ldy + col); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-            if (p.raw_store) *reinterpret_cast<float4*>(geo.y + (long long)ro * p.ldy + col) = v;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (q >= p.ngate) break;
-                const float4 y4 = *reinterpret_cast<const float4*>(p.gate[q].y + (long long)ro * p.gate[q].ldy + col);
-                float4 g;
-                g.x = fmaf(sc[q].x, y4.x, sh[q].x) > 0.f ? v.x : 0.f; g.y = fmaf(sc[q].y, y4.y, sh[q].y) > 0.f ? v.y : 0.f;
-                g.z = fmaf(sc[q].z, y4.z, sh[q].z) > 0.f ? v.z : 0.f; g.w = fmaf(sc[q].w, y4.w, sh[q].w) > 0.f ? v.w : 0.f;
-                *reinterpret_cast<float4*>(p.gate[q].out + (long long)ro * p.gate[q].ldo + col) = g;
-                s[q].x += g.x; s[q].y += g.y; s[q].z += g.z; s[q].w += g.w;
-                sx[q].x = fmaf(g.x, (y4.x - mu[q].x) * iv[q].x, sx[q].x); sx[q].y = fmaf(g.y, (y4.y - mu[q].y) * iv[q].y, sx[q].y);
-                sx[q].z = fmaf(g.z, (y4.z - mu[q].z) * iv[q].z, sx[q].z); sx[q].w = fmaf(g.w, (y4.w - mu[q].w) * iv[q].w, sx[q].w);
-            }
-        }
-        __syncthreads();                        // everyone is done with the tile: sred may be reused
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (q >= p.ngate) break;
-#pragma unroll
-            for (int o = F4R; o < 64; o <<= 1) {
-                const float4 a = shfl_xor4(s[q], o), b = shfl_xor4(sx[q], o);
-                s[q].x += a.x; s[q].y += a.y; s[q].z += a.z; s[q].w += a.w;
-                sx[q].x += b.x; sx[q].y += b.y; sx[q].z += b.z; sx[q].w += b.w;
-            }
-            if (lane < F4R) {
-                float* d = sred + ((q * 4 + wave) * BN + c4) * 2;
-                d[0] = s[q].x; d[1] = sx[q].x; d[2] = s[q].y; d[3] = sx[q].y; d[4] = s[q].z; d[5] = sx[q].z; d[6] = s[q].w; d[7] = sx[q].w;
-            }
-        }
-        __syncthreads();
-        if (tid < BN && (n0 + tid) < p.Nc) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (q >= p.ngate) break;
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) { t1 += sred[((q * 4 + w) * BN + tid) * 2]; t2 += sred[((q * 4 + w) * BN + tid) * 2 + 1]; }
-                float* dst = p.gate[q].part + ((size_t)mt * p.Nc + n0 + tid) * 2;
-                dst[0] = t1; dst[1] = t2;
-            }
-        }
-        return;
-    }
-
-    // -- output rows: bias, optional accumulate, row-wise float4 stores; the stored values go back to the tile for the
-    //    statistics pass --------------------------------------------------------------------------------------------
-    const bool want_stats = geo.statpart != nullptr || p.eb.mode != 0;
-#pragma unroll 4
-    for (int i = tid; i < BM * F4R; i += 256) {
-        const int r = i / F4R, c4 = (i - r * F4R) * 4;
-        const int ro = rowIdx[r];
-        const int col = n0 + c4;
-        if (ro < 0 || col >= p.Nc) continue;
-        float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
-        if (geo.bias) { const float4 b = *reinterpret_cast<const float4*>(geo.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-        if (want_stats) *reinterpret_cast<float4*>(tile + r * LDT + c4) = v;
-        float* dst = geo.y + (long long)ro * p.ldy + col;
-        if (p.accum) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        *reinterpret_cast<float4*>(dst) = v;
-    }
-    if (want_stats) {
-        // per-channel (sum, sumsq) over this tile's valid rows: 4 row groups x BN columns, folded in a fixed order
-        __syncthreads();
-        constexpr int RG = 256 / BN, RPG = BM / RG;
-        const int col = tid % BN, rg = tid / BN;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-        for (int r = rg * RPG; r < (rg + 1) * RPG; ++r)
-            if (rowIdx[r] >= 0) { const float v = tile[r * LDT + col]; s1 += v; s2 = fmaf(v, v, s2); }
-        sred[(rg * BN + col) * 2] = s1; sred[(rg * BN + col) * 2 + 1] = s2;
-        __syncthreads();
-        if (tid < BN && (n0 + tid) < p.Nc) {
-            float t1 = sred[tid * 2], t2 = sred[tid * 2 + 1];
-#pragma unroll
-            for (int g = 1; g < RG; ++g) { t1 += sred[(g * BN + tid) * 2]; t2 += sred[(g * BN + tid) * 2 + 1]; }
-            if (geo.statpart) {
-                float* dst = geo.statpart + ((size_t)(geo.stat_base + mt) * p.Nc + n0 + tid) * 2;
-                dst[0] = t1; dst[1] = t2;
-            }
-            if (p.eb.mode) {
-                // publish: one 8-byte {value, epoch} granule per statistic, write-through, no flag and no drain -- whoever
-                // sweeps sees either the previous launch's tag or this value
-                unsigned long long* g = p.eb.xch + ((size_t)mt * p.Nc + n0 + tid) * 2;
-                const unsigned long long tag = (unsigned long long)p.eb.epoch << 32;
-                __hip_atomic_store(g, tag | __float_as_uint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g + 1, tag | __float_as_uint(t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    if (p.eb.mode) {
-        // ---- BatchNorm of this conv's output, here (BnEpi, p3d_kernels.h): sweep the granules of every row tile of this
-        //      column range, fold in tile order (double), normalise the tile in LDS, store z ------------------------------
-        const int mtiles = (int)((M + BM - 1) / BM);
-        double* dsum = reinterpret_cast<double*>(sred);          // [2][BN] column totals   (sred is free again after the barrier below)
-        float* coef = sred + 4 * BN;                             // [2][BN] scale, shift
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int c = tid % BN, st = tid / BN;
-            double tot = 0.0;
-            if (n0 + c < p.Nc) {
-                const unsigned long long* g = p.eb.xch + ((size_t)(n0 + c)) * 2 + st;
-                const size_t stride = (size_t)p.Nc * 2;
-                unsigned long long v[P3D_EB_MAX_MTILES];
-                const unsigned long long t_start = wall_clock64();
-                bool ok = false;
-                while (true) {
-#pragma unroll
-                    for (int q = 0; q < P3D_EB_MAX_MTILES; ++q)
-                        v[q] = __hip_atomic_load(g + (size_t)min(q, mtiles - 1) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = true;
-#pragma unroll
-                    for (int q = 0; q < P3D_EB_MAX_MTILES; ++q) ok = ok && (unsigned)(v[q] >> 32) == p.eb.epoch;
-                    if (ok) break;
-                    if (wall_clock64() - t_start > 200000000ull) { atomicOr(p.eb.err, 1u); break; }      // 2 s at 100 MHz: give up, loudly
-                    __builtin_amdgcn_s_sleep(4);
-                }
-#pragma unroll
-                for (int q = 0; q < P3D_EB_MAX_MTILES; ++q)
-                    if (q < mtiles) tot += (double)__uint_as_float((unsigned)v[q]);
-            }
-            dsum[st * BN + c] = tot;
-        }
-        __syncthreads();
-        if (tid < BN && (n0 + tid) < p.Nc) {
-            const int k = n0 + tid;
-            const double mean = dsum[tid] * p.eb.inv_m;
-            double var = dsum[BN + tid] * p.eb.inv_m - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float meanf = (float)mean, varf = (float)var;
-            const float inv = 1.0f / sqrtf(varf + p.eb.eps);
-            const float sc = p.eb.gamma[k] * inv;
-            const float sh = p.eb.beta[k] - meanf * sc;
-            coef[tid] = sc; coef[BN + tid] = sh;
-            if (mt == 0) {          // one publisher per column range; every block of the range holds the same bits
-                p.eb.scale[k] = sc; p.eb.shift[k] = sh; p.eb.mean[k] = meanf; p.eb.invstd[k] = inv;
-                if (p.eb.update_moving) {      // moving -= (moving - batch) * (1 - 0.99)   (biased variance)
-                    p.eb.moving_mean[k] -= (p.eb.moving_mean[k] - meanf) * (1.0f - 0.99f);
-                    p.eb.moving_var[k] -= (p.eb.moving_var[k] - varf) * (1.0f - 0.99f);
-                }
-            }
-        }
-        __syncthreads();
-        const int ebm = p.eb.mode;
-#pragma unroll 4
-        for (int i = tid; i < BM * F4R; i += 256) {
-            const int r = i / F4R, c4 = (i - r * F4R) * 4;
-            const int ro = rowIdx[r];
-            const int col = n0 + c4;
-            if (ro < 0 || col >= p.Nc) continue;
-            const float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
-            const float4 sc = *reinterpret_cast<const float4*>(coef + c4), sh = *reinterpret_cast<const float4*>(coef + BN + c4);
-            float4 u = make_float4(fmaf(sc.x, v.x, sh.x), fmaf(sc.y, v.y, sh.y), fmaf(sc.z, v.z, sh.z), fmaf(sc.w, v.w, sh.w));
-            float4 z;
-            if (ebm == 1) {
-                z = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
-            } else {
-                const float4 rr = *reinterpret_cast<const float4*>(p.eb.r + (long long)ro * p.eb.ldr + col);
-                if (ebm == 2) z = make_float4(fmaxf(u.x + rr.x, 0.f), fmaxf(u.y + rr.y, 0.f), fmaxf(u.z + rr.z, 0.f), fmaxf(u.w + rr.w, 0.f));
-                else z = make_float4(rr.x + fmaxf(u.x, 0.f), rr.y + fmaxf(u.y, 0.f), rr.z + fmaxf(u.z, 0.f), rr.w + fmaxf(u.w, 0.f));
-            }
-            *reinterpret_cast<float4*>(p.eb.z + (long long)ro * p.eb.ldz + col) = z;
-        }
-    }
+    igemm_tile_epilogue<BM, BN>(p, geo, tile, sred, rowIdx, mt, n0, M, bias4);
 }
 
 // Block -> tile so that the blocks of one XCD (block index mod 8) work on CONSECUTIVE tiles: the N tiles of one row range and
@@ -932,9 +740,10 @@ __device__ __forceinline__ int xcd_tile(int b, int T, int min_tiles) {
 
 template <int BM, int BN, bool WT, bool F16 = false, int AT = 0>
 __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
+    p3d_warm_kernargs<IgemmArgs>();
     Geo geo;
     geo.Gd = p.Gd; geo.Gh = p.Gh; geo.Gw = p.Gw; geo.fGd = p.fGd; geo.fGh = p.fGh; geo.fGw = p.fGw;
-    geo.ood = p.ood; geo.ooh = p.ooh; geo.oow = p.oow; geo.stat_base = p.stat_base; geo.ntaps = p.ntaps; geo.taps = p.taps;
+    geo.ood = p.ood; geo.ooh = p.ooh; geo.oow = p.oow; geo.stat_base = p.stat_base; geo.ntaps = p.ntaps; geo.taps = p3d_kernarg_taps(offsetof(IgemmArgs, taps));
     geo.w = p.w; geo.bias = p.bias; geo.y = p.y; geo.statpart = p.statpart;
     geo.nsplit = p.nsplit; geo.slab = p.slab; geo.cnt = p.cnt;
     const int tile = p.nsplit == 1 ? xcd_tile((int)blockIdx.x, (int)gridDim.x, p.xcd_min_tiles) : (int)blockIdx.x;
@@ -944,6 +753,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmArgs p) {
 // first (a class with eight taps runs eight times as long per tile as one with a single tap: the late blocks are the short ones)
 template <int BM, int BN, bool WT, bool F16 = false>
 __global__ __launch_bounds__(256) void igemm2_group_kernel(const IgemmGroupArgs g) {
+    p3d_warm_kernargs<IgemmArgs>();            // the part every class shares (the class tables follow it)
     int c = 0;
 #pragma unroll
     for (int q = 1; q < P3D_IGEMM_CLASSES; ++q)
@@ -951,7 +761,7 @@ __global__ __launch_bounds__(256) void igemm2_group_kernel(const IgemmGroupArgs 
     Geo geo;
     geo.Gd = g.cls[c].Gd; geo.Gh = g.cls[c].Gh; geo.Gw = g.cls[c].Gw; geo.fGd = g.cls[c].fGd; geo.fGh = g.cls[c].fGh; geo.fGw = g.cls[c].fGw;
     geo.ood = g.cls[c].ood; geo.ooh = g.cls[c].ooh; geo.oow = g.cls[c].oow; geo.stat_base = g.cls[c].stat_base; geo.ntaps = g.cls[c].ntaps;
-    geo.taps = g.cls[c].taps;
+    geo.taps = p3d_kernarg_taps(offsetof(IgemmGroupArgs, cls) + (size_t)c * sizeof(IgemmClass) + offsetof(IgemmClass, taps));
     geo.w = g.cls[c].w; geo.bias = g.cls[c].bias; geo.y = g.cls[c].y; geo.statpart = g.cls[c].statpart;
     // K-sliced classes: consecutive blocks of a class are the slices of one tile
     // (a tail class starts at tile0 of its grid: the body indexes scratch by tile, so the class's share is rebased by tile0)
@@ -1021,6 +831,11 @@ hipError_t launch_t(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) 
         const hipError_t e = p3d_stream_scratch(s, (size_t)tiles * splits * BM * BN, (size_t)tiles, &a.slab, &a.cnt);
         if (e != hipSuccess) return e;
     }
+    if (a.eb.mode) {
+        if (BM != 64 || BN != 64) return hipErrorInvalidValue;
+        const hipError_t e = p3d_stream_xch(s, (size_t)((M + BM - 1) / BM) * a.Nc * 2, &a.eb.xch, &a.eb.epoch, &a.eb.err);
+        if (e != hipSuccess) return e;
+    }
     const dim3 grid((unsigned)tiles, (unsigned)splits);
     // forward convs ([K][Nc] weights) take the relu transforms, input gradients ([Nc][K] weights) the gradient transform
     if (a.wT) {
@@ -1036,8 +851,12 @@ hipError_t launch_t(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) 
     }
 }
 
-// ---- per-stream scratch (partial tiles + arrival counters) -----------------------------------------------------
-struct Scratch { float* slab = nullptr; size_t slab_floats = 0; unsigned* cnt = nullptr; size_t counters = 0; };
+// ---- per-stream scratch (partial tiles + arrival counters; granules of the epilogue BatchNorm) ------------------------
+struct Scratch {
+    float* slab = nullptr; size_t slab_floats = 0; unsigned* cnt = nullptr; size_t counters = 0;
+    unsigned long long* xch = nullptr; size_t granules = 0; unsigned epoch = 0;
+};
+unsigned* g_eb_err = nullptr;              // one device word for every stream: a granule sweep gave up
 std::vector<void*> g_scratch_allocs;       // every buffer ever handed out (outgrown ones stay valid until shutdown)
 std::map<hipStream_t, Scratch> g_scratch;
 std::mutex g_scratch_mutex;
@@ -1070,6 +889,41 @@ hipError_t p3d_stream_scratch(hipStream_t s, size_t slab_floats, size_t counters
     return hipSuccess;
 }
 
+hipError_t p3d_stream_xch(hipStream_t s, size_t granules, unsigned long long** xch, unsigned* epoch, unsigned** err) {
+    std::lock_guard<std::mutex> g(g_scratch_mutex);
+    Scratch& sc = g_scratch[s];
+    if (!g_eb_err) {
+        unsigned* p = nullptr;
+        hipError_t e = hipMalloc((void**)&p, 64);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(p, 0, 64, s);
+        if (e != hipSuccess) return e;
+        g_eb_err = p; g_scratch_allocs.push_back(p);
+    }
+    if (granules > sc.granules) {
+        const size_t want = granules * 2 + 4096;
+        unsigned long long* p = nullptr;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(unsigned long long));
+        if (e != hipSuccess) return e;
+        // tag 0 = "never written": epochs start at 1.  In stream order, like the counters above.
+        e = hipMemsetAsync(p, 0, want * sizeof(unsigned long long), s);
+        if (e != hipSuccess) return e;
+        sc.xch = p; sc.granules = want; g_scratch_allocs.push_back(p);
+    }
+    if (++sc.epoch == 0) sc.epoch = 1;        // (a wrapped tag could only match a granule written 2^32 launches ago on this stream)
+    *xch = sc.xch; *epoch = sc.epoch; *err = g_eb_err;
+    return hipSuccess;
+}
+
+long long p3d_eb_timeouts() {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    std::lock_guard<std::mutex> g(g_scratch_mutex);
+    if (!g_eb_err) return 0;
+    unsigned v = 0;
+    if (hipMemcpy(&v, g_eb_err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
+
 // Test hook: arrival counters that are not zero although nothing is in flight (every K-sliced launch must leave its counters
 // as it found them); -1 on a HIP error.
 long long p3d_scratch_dirty_counters() {
@@ -1091,6 +945,7 @@ void p3d_release_scratch() {
     for (void* p : g_scratch_allocs) hipFree(p);
     g_scratch_allocs.clear();
     g_scratch.clear();
+    g_eb_err = nullptr;
 }
 
 namespace {
@@ -1157,6 +1012,16 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int) {
     P3dIgemmPlan pl = heuristic_plan(a);
     PlanOverride ov;
     { std::lock_guard<std::mutex> g(g_plan_mutex); ov = g_override; }
+    if (ov.tile < 0 && ov.splits < 1 && !a.ngate) {      // (any override, tile 3 included, keeps the launch on the pipelined kernel)
+        // few output positions (stage 3): one wave per 32x32 tile, no K-slices across blocks (conv_small.hip)
+        const int sh = p3d_convsm_shape(a);
+        if (sh) {
+            pl.small = sh; pl.splits = 1;
+            pl.bm = sh == 2 ? 64 : 32; pl.bn = sh == 1 ? 32 : 64;
+            pl.name = sh == 1 ? "convsm_kernel<1,1,4>" : (sh == 2 ? "convsm_kernel<2,2,1>" : "convsm_kernel<1,2,2>");
+            return pl;
+        }
+    }
     const int steps = a.ntaps * ((a.K + BK - 1) / BK);
     if (ov.tile == 0) { pl.bm = 64; pl.bn = 64; }
     else if (ov.tile == 1) { pl.bm = 128; pl.bn = 64; }
@@ -1192,6 +1057,8 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStr
     for (int q = 0; q < a.ngate; ++q)
         if (!a.gate[q].y || !a.gate[q].out || !a.gate[q].part || (a.gate[q].ldy & 3) || (a.gate[q].ldo & 3)) return hipErrorInvalidValue;
     if (a.ngate && a.statpart) return hipErrorInvalidValue;
+    if (pl.small) return p3d_launch_convsm(a, pl.small, s);
+    if (a.eb.mode && !p3d_igemm2_eb_ok(a, pl)) return hipErrorInvalidValue;
     if (p3d_igemm2_tail_split(a, pl)) return p3d_launch_igemm2_group(&a, 1, pl, s);      // full rounds + a K-sliced tail class
     if (pl.bm == 128 && pl.bn == 128) return launch_t<128, 128>(a, pl, s);
     if (pl.bm == 128 && pl.bn == 64) return launch_t<128, 64>(a, pl, s);
@@ -1200,7 +1067,7 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStr
 
 // ---- grouped launch of residue classes ---------------------------------------------------------------------------------
 bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& pl) {
-    if (n < 2 || n > P3D_IGEMM_CLASSES) return false;
+    if (n < 2 || n > P3D_IGEMM_CLASSES || pl.small) return false;
     for (int i = 0; i < n; ++i) {
         const IgemmArgs& a = v[i];
         // shared: the gathered operand and every extent / stride; per class: grid, offsets, taps, weights, bias, output, statistics
@@ -1256,8 +1123,25 @@ hipError_t launch_group_t(IgemmGroupArgs& g, const long long* tiles, hipStream_t
 }  // namespace
 
 
+// May this launch normalise its own output (BnEpi)?  Every output tile's last arriver waits for the other row tiles of its
+// column range while holding a CU slot: all of them must be able to sit on the chip beside the blocks still to run.
+bool p3d_igemm2_eb_ok(const IgemmArgs& a, const P3dIgemmPlan& pl) {
+    if (pl.small || pl.bm != 64 || pl.bn != 64 || a.accum || a.ngate || a.at_mode == P3D_AT_GRAD) return false;
+    const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
+    const long long mt = (M + 63) / 64, tiles = mt * ((a.Nc + 63) / 64);
+    if (mt > P3D_EB_MAX_MTILES || tiles > P3D_EB_MAX_TILES) return false;
+    if (a.eb.mode < 0 || a.eb.mode > 3) return false;
+    if (a.eb.mode) {
+        if (!a.eb.z || (a.eb.ldz & 3) || !a.eb.gamma || !a.eb.beta || !a.eb.scale || !a.eb.shift || !a.eb.mean || !a.eb.invstd) return false;
+        if (a.eb.mode >= 2 && (!a.eb.r || (a.eb.ldr & 3))) return false;
+        if (a.eb.update_moving && (!a.eb.moving_mean || !a.eb.moving_var)) return false;
+    }
+    return !p3d_igemm2_tail_split(a, pl);
+}
+
 // Would the tail of this single launch be cut into K-slices (then it goes out through the grouped kernel)?
 bool p3d_igemm2_tail_split(const IgemmArgs& a, const P3dIgemmPlan& pl) {
+    if (pl.small) return false;
     if (a.at_mode || a.ngate || pl.splits > 1 || !tail_split_enabled()) return false;
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const long long tiles = ((M + pl.bm - 1) / pl.bm) * ((a.Nc + pl.bn - 1) / pl.bn);

@@ -950,7 +950,12 @@ struct p3d_handle {
             if (sibling && !c.dry && !(c.fuse && cf.at) && ntap > 0 && !stem) {
                 IgemmArgs a = igemm_conv_forward(g, x->N, x->p, x->ld, Cin, y->p, y->ld, Cout, w->p, bias ? bias->p : nullptr, 0, false);
                 sibling_prepare(c, a);
-                if (sibling == 1) { sib_pending.push_back(a); return; }       // first of the pair: wait for the second
+                if (sibling == 1) {       // first of the pair: wait for the second (a stale entry would be a third class of the next pair)
+                    if (!sib_pending.empty()) throw P3dError("sibling conv " + opname + ": an earlier pair never sent its launch");
+                    sib_pending.push_back(a);
+                    return;
+                }
+                if (sib_pending.size() != 1) throw P3dError("sibling conv " + opname + " has no first sibling waiting");
                 sib_pending.push_back(a);
                 std::vector<IgemmArgs> v;
                 v.swap(sib_pending);
@@ -958,7 +963,8 @@ struct p3d_handle {
                 if (p3d_igemm2_groupable(v.data(), (int)v.size(), pl)) {
                     double fl = 0, by = 0;
                     for (auto& q : v) { double f1, b1; igemm_work(q, f1, b1); fl += f1; by += b1; }
-                    launch(c, "igemm2_group_kernel<64,64>(siblings)", fl, by, [&]() { return p3d_launch_igemm2_group(v.data(), (int)v.size(), pl, c.s); });
+                    const std::string kn = std::string("igemm2_group_kernel<") + std::to_string(pl.bm) + "," + std::to_string(pl.bn) + ">(siblings)";
+                    launch(c, kn.c_str(), fl, by, [&]() { return p3d_launch_igemm2_group(v.data(), (int)v.size(), pl, c.s); });
                 } else {
                     for (auto& q : v) launch_igemm(c, q, 1);
                 }
@@ -2247,6 +2253,7 @@ struct p3d_handle {
         fflush(stderr);
     }
     void run_forward(const Ctx& c) {
+        sib_pending.clear();          // (a pass that threw between the two siblings of an ST_B pair must not hand its launch to this one)
         if (stats_count) HIPCHECK(hipMemsetAsync(stats_arena, 0, (size_t)stats_count * sizeof(double), c.s));
         if (zf_bytes) HIPCHECK(hipMemsetAsync(zf, 0, zf_bytes, c.s));
         Ctx cz = c; cz.z0 = zf; cz.z1 = zf + zf_bytes;
@@ -2928,6 +2935,7 @@ int p3d_block_forward(p3d_handle* h, int block_id, const float* in, int64_t in_c
     HIPCHECK(hipMemcpy2DAsync(a->p, (size_t)a->ld * 4, in, (size_t)a->C * 4, (size_t)a->C * 4, (size_t)a->rows(), hipMemcpyHostToDevice, h->stream));
     Ctx c; c.training = true; c.s = h->stream; c.fuse = h->fuse_bn;
     h->last_forward_fused = c.fuse;
+    h->sib_pending.clear();
     if (h->stats_count) HIPCHECK(hipMemsetAsync(h->stats_arena, 0, (size_t)h->stats_count * sizeof(double), c.s));
     for (size_t i = it->second.op0; i < it->second.op1; ++i) h->ops[i].fwd(c);      // (no zero arena: ops zero what they slice)
     h->download_act(b, out);
@@ -2945,6 +2953,7 @@ int p3d_block_backward(p3d_handle* h, int block_id, const float* in, int64_t in_
     HIPCHECK(hipSetDevice(h->cfg.device));
     HIPCHECK(hipMemcpy2DAsync(a->p, (size_t)a->ld * 4, in, (size_t)a->C * 4, (size_t)a->C * 4, (size_t)a->rows(), hipMemcpyHostToDevice, h->stream));
     Ctx c; c.training = true; c.s = h->stream; c.fuse = false;
+    h->sib_pending.clear();
     h->last_forward_fused = false;
     if (h->stats_count) HIPCHECK(hipMemsetAsync(h->stats_arena, 0, (size_t)h->stats_count * sizeof(double), c.s));
     for (size_t i = it->second.op0; i < it->second.op1; ++i) h->ops[i].fwd(c);

@@ -56,6 +56,35 @@ __device__ __forceinline__ unsigned p3d_div(unsigned n, P3dFastDiv f) { return f
 // priority 1 and 3 alike; profiles/r03_prio_ab.json).
 #if defined(__HIPCC__)
 #define P3D_CHAIN_PRIO() __builtin_amdgcn_s_setprio(2)
+// Kernel arguments arrive through the scalar cache, one 64-byte line per first touch, and hipcc reads them where they are used:
+// a kernel with a 1 KB argument struct walks into one cold line after another (measured: 13 dependent s_load / s_waitcnt round
+// trips, 2.3 us, between the entry of the pipelined conv kernel and its first operand load).  Touch every line of the struct
+// at entry, all loads in flight together: one miss latency, and what follows hits the cache.
+// ONE asm statement per kernel, the wait inside it: scalar loads return out of order and hipcc does not count an asm statement's
+// loads, so a load still in flight behind the statement could land in a register the compiler has meanwhile given to
+// something else (it did: wrong convolutions).  All loads of the statement target the same scratch SGPR.
+typedef const unsigned __attribute__((address_space(4))) p3d_karg_t;
+#define P3D_WL(off) "s_load_dword %0, %1, " #off "\n\t"
+#define P3D_WL4(a, b, c, d) P3D_WL(a) P3D_WL(b) P3D_WL(c) P3D_WL(d)
+template <int LINES>
+__device__ __forceinline__ void p3d_warm_kernarg_lines() {
+    p3d_karg_t* ka = (p3d_karg_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t;
+    // the largest supported count that stays inside the struct (never a load past the arguments)
+    if constexpr (LINES >= 17)
+        asm volatile(P3D_WL4(0x0, 0x40, 0x80, 0xc0) P3D_WL4(0x100, 0x140, 0x180, 0x1c0) P3D_WL4(0x200, 0x240, 0x280, 0x2c0)
+                     P3D_WL4(0x300, 0x340, 0x380, 0x3c0) P3D_WL(0x400) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(ka) : "memory");
+    else if constexpr (LINES >= 8)
+        asm volatile(P3D_WL4(0x0, 0x40, 0x80, 0xc0) P3D_WL4(0x100, 0x140, 0x180, 0x1c0) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(ka) : "memory");
+    else if constexpr (LINES >= 6)
+        asm volatile(P3D_WL4(0x0, 0x40, 0x80, 0xc0) P3D_WL(0x100) P3D_WL(0x140) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(ka) : "memory");
+    else if constexpr (LINES >= 4)
+        asm volatile(P3D_WL4(0x0, 0x40, 0x80, 0xc0) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(ka) : "memory");
+    else if constexpr (LINES >= 2)
+        asm volatile(P3D_WL(0x0) P3D_WL(0x40) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(ka) : "memory");
+}
+template <class Args>
+__device__ __forceinline__ void p3d_warm_kernargs() { p3d_warm_kernarg_lines<(int)((sizeof(Args) + 63) / 64)>(); }
 #endif
 
 struct P3dTap {
@@ -192,6 +221,7 @@ struct IgemmGroupArgs {
 // Tile and split-K choice of the pipelined kernel (conv_igemm2.hip)
 struct P3dIgemmPlan {
     int bm = 64, bn = 64, splits = 1;
+    int small = 0;        // > 0: the small-M kernel (conv_small.hip) in this wave arrangement; bm / bn are its tile
     const char* name = "";
 };
 // number of output-tile rows (= statistics partials) a launch with this plan produces
@@ -250,7 +280,10 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipSt
 bool p3d_igemm2_tail_split(const IgemmArgs& a, const P3dIgemmPlan& pl);      // a single launch whose last round gets K-sliced (goes out grouped)
 bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& plan);
 hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan& plan, hipStream_t s);
-void p3d_igemm2_override(int tile, int splits);   // test / tools hook: force the tile (0: 64x64, 1: 128x64, 2: 128x128) and the K-slice count; -1 / 0 = no override
+// the small-M kernel (conv_small.hip): wave arrangement for this launch (0: not its case) and the launch itself
+int p3d_convsm_shape(const IgemmArgs& a);
+hipError_t p3d_launch_convsm(const IgemmArgs& a, int shape, hipStream_t s);
+void p3d_igemm2_override(int tile, int splits);   // test / tools hook: force the tile (0: 64x64, 1: 128x64, 2: 128x128 of the pipelined kernel -- the small-M kernel is then off) and the K-slice count; -1 / 0 = no override
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s);   // up to P3D_WGRAD_GROUP problems, one launch
 const char* p3d_wgrad2_variant(const WgradArgs& a);

@@ -98,6 +98,12 @@ POOL_CASES = [
     ((2, 4, 12, 12, 16), (2, 3, 3), (2, 2, 2)),     # pool1
     ((2, 4, 6, 6, 32), (2, 1, 1), (2, 1, 1)),       # temporal pools
     ((1, 3, 7, 9, 8), (2, 3, 3), (2, 2, 2)),        # odd extents: SAME padding on every axis
+    # border cells of the gather backward (a fault at 0x1000 while its two-window fast path was written -- the
+    # candidate windows of a border cell lie at output index -1 and at index Do, and the first version formed their table
+    # and gradient addresses before looking at the validity flag).  k = 4, s = 2 on 8 cells: pad 1 before / 1 after, so cell 0
+    # sees window -1 and cell 7 sees window 4 = Do on every axis, on the fast path (k <= 2s); k = 5 takes the general loops.
+    ((1, 8, 8, 8, 8), (4, 4, 4), (2, 2, 2)),
+    ((1, 8, 8, 8, 4), (5, 5, 5), (2, 2, 2)),
 ]
 
 
