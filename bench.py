@@ -179,8 +179,6 @@ def main():
                     help="unet++ds: how the attention cores run (p3d_set_attention_mode)")
     ap.add_argument("--bn-fusion", default="default", choices=["default", "off", "fwd", "full"],
                     help="A/B runs: BatchNorm passes of their own / fused into the convs in the forward pass / in both passes")
-    ap.add_argument("--small-conv", default="on", choices=["on", "off"],
-                    help="A/B runs: off keeps stage 3's convs on the pipelined kernel with K-slices (p3d_debug_force_plan(3, ...))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--dump-launches", default=None, help="write every launch record of the profiled step to this CSV")
@@ -210,9 +208,6 @@ def main():
     rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1"
     sess = P3DSession(args.structure, batch=B, frames=T, height=S, width=S, device=0 if rehearsal else local_rank,
                       world_size=world, rank=rank, seed=1)
-    if args.small_conv == "off":
-        from sap3d_tensorflow_amd import lib
-        lib().p3d_debug_force_plan(3, 0, 0, 0)
     if args.pointwise == "fp16":
         sess.set_pointwise_fp16(True)
     if args.attention != "auto":
@@ -278,7 +273,7 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "dropout": 0.5},
             "model_tflops": round(value * FLOP_PER_CLIP_FWD_BWD * (T / 16.0) * (S / 112.0) ** 2 / 1e12, 2) if args.structure == "unet" else None,
             "final_loss": loss,
-            "bn_fusion": args.bn_fusion, "attention": args.attention, "small_conv": args.small_conv,
+            "bn_fusion": args.bn_fusion, "attention": args.attention,
             "launches_per_step": len(recs),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
             "host_enqueue_ms_one_step_empty_queue": round(1e3 * t_one, 3),

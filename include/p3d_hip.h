@@ -186,8 +186,7 @@ int p3d_debug_bucket_audit(p3d_handle* h, float dropout_rate, uint64_t seed, int
 int64_t p3d_debug_dirty_counters(void);
 
 /* Test hook (process-wide): force the tile / K-slice plan of the convolution kernels where a problem allows it, so that
- * every instantiation is reachable from the op-level parity tests.  igemm_tile: 0 = 64x64, 1 = 128x64, 2 = 128x128 of the
- * pipelined kernel, 3 = the pipelined kernel with the plan's own tile (the small-M kernel of stage 3 off: A/B runs),
+ * every instantiation is reachable from the op-level parity tests.  igemm_tile: 0 = 64x64, 1 = 128x64, 2 = 128x128,
  * -1 = the plan's choice; igemm_splits: K-slices, 0 = the plan's; wgrad_tm / wgrad_tn: 64 or 128, 0 = the plan's. */
 int p3d_debug_force_plan(int igemm_tile, int igemm_splits, int wgrad_tm, int wgrad_tn);
 

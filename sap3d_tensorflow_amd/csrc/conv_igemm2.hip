@@ -831,11 +831,6 @@ hipError_t launch_t(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) 
         const hipError_t e = p3d_stream_scratch(s, (size_t)tiles * splits * BM * BN, (size_t)tiles, &a.slab, &a.cnt);
         if (e != hipSuccess) return e;
     }
-    if (a.eb.mode) {
-        if (BM != 64 || BN != 64) return hipErrorInvalidValue;
-        const hipError_t e = p3d_stream_xch(s, (size_t)((M + BM - 1) / BM) * a.Nc * 2, &a.eb.xch, &a.eb.epoch, &a.eb.err);
-        if (e != hipSuccess) return e;
-    }
     const dim3 grid((unsigned)tiles, (unsigned)splits);
     // forward convs ([K][Nc] weights) take the relu transforms, input gradients ([Nc][K] weights) the gradient transform
     if (a.wT) {
@@ -851,12 +846,8 @@ hipError_t launch_t(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStream_t s) 
     }
 }
 
-// ---- per-stream scratch (partial tiles + arrival counters; granules of the epilogue BatchNorm) ------------------------
-struct Scratch {
-    float* slab = nullptr; size_t slab_floats = 0; unsigned* cnt = nullptr; size_t counters = 0;
-    unsigned long long* xch = nullptr; size_t granules = 0; unsigned epoch = 0;
-};
-unsigned* g_eb_err = nullptr;              // one device word for every stream: a granule sweep gave up
+// ---- per-stream scratch (partial tiles + arrival counters) -----------------------------------------------------
+struct Scratch { float* slab = nullptr; size_t slab_floats = 0; unsigned* cnt = nullptr; size_t counters = 0; };
 std::vector<void*> g_scratch_allocs;       // every buffer ever handed out (outgrown ones stay valid until shutdown)
 std::map<hipStream_t, Scratch> g_scratch;
 std::mutex g_scratch_mutex;
@@ -889,41 +880,6 @@ hipError_t p3d_stream_scratch(hipStream_t s, size_t slab_floats, size_t counters
     return hipSuccess;
 }
 
-hipError_t p3d_stream_xch(hipStream_t s, size_t granules, unsigned long long** xch, unsigned* epoch, unsigned** err) {
-    std::lock_guard<std::mutex> g(g_scratch_mutex);
-    Scratch& sc = g_scratch[s];
-    if (!g_eb_err) {
-        unsigned* p = nullptr;
-        hipError_t e = hipMalloc((void**)&p, 64);
-        if (e != hipSuccess) return e;
-        e = hipMemsetAsync(p, 0, 64, s);
-        if (e != hipSuccess) return e;
-        g_eb_err = p; g_scratch_allocs.push_back(p);
-    }
-    if (granules > sc.granules) {
-        const size_t want = granules * 2 + 4096;
-        unsigned long long* p = nullptr;
-        hipError_t e = hipMalloc((void**)&p, want * sizeof(unsigned long long));
-        if (e != hipSuccess) return e;
-        // tag 0 = "never written": epochs start at 1.  In stream order, like the counters above.
-        e = hipMemsetAsync(p, 0, want * sizeof(unsigned long long), s);
-        if (e != hipSuccess) return e;
-        sc.xch = p; sc.granules = want; g_scratch_allocs.push_back(p);
-    }
-    if (++sc.epoch == 0) sc.epoch = 1;        // (a wrapped tag could only match a granule written 2^32 launches ago on this stream)
-    *xch = sc.xch; *epoch = sc.epoch; *err = g_eb_err;
-    return hipSuccess;
-}
-
-long long p3d_eb_timeouts() {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    std::lock_guard<std::mutex> g(g_scratch_mutex);
-    if (!g_eb_err) return 0;
-    unsigned v = 0;
-    if (hipMemcpy(&v, g_eb_err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return v;
-}
-
 // Test hook: arrival counters that are not zero although nothing is in flight (every K-sliced launch must leave its counters
 // as it found them); -1 on a HIP error.
 long long p3d_scratch_dirty_counters() {
@@ -945,7 +901,6 @@ void p3d_release_scratch() {
     for (void* p : g_scratch_allocs) hipFree(p);
     g_scratch_allocs.clear();
     g_scratch.clear();
-    g_eb_err = nullptr;
 }
 
 namespace {
@@ -1012,16 +967,6 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int) {
     P3dIgemmPlan pl = heuristic_plan(a);
     PlanOverride ov;
     { std::lock_guard<std::mutex> g(g_plan_mutex); ov = g_override; }
-    if (ov.tile < 0 && ov.splits < 1 && !a.ngate) {      // (any override, tile 3 included, keeps the launch on the pipelined kernel)
-        // few output positions (stage 3): one wave per 32x32 tile, no K-slices across blocks (conv_small.hip)
-        const int sh = p3d_convsm_shape(a);
-        if (sh) {
-            pl.small = sh; pl.splits = 1;
-            pl.bm = sh == 2 ? 64 : 32; pl.bn = sh == 1 ? 32 : 64;
-            pl.name = sh == 1 ? "convsm_kernel<1,1,4>" : (sh == 2 ? "convsm_kernel<2,2,1>" : "convsm_kernel<1,2,2>");
-            return pl;
-        }
-    }
     const int steps = a.ntaps * ((a.K + BK - 1) / BK);
     if (ov.tile == 0) { pl.bm = 64; pl.bn = 64; }
     else if (ov.tile == 1) { pl.bm = 128; pl.bn = 64; }
@@ -1057,8 +1002,6 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStr
     for (int q = 0; q < a.ngate; ++q)
         if (!a.gate[q].y || !a.gate[q].out || !a.gate[q].part || (a.gate[q].ldy & 3) || (a.gate[q].ldo & 3)) return hipErrorInvalidValue;
     if (a.ngate && a.statpart) return hipErrorInvalidValue;
-    if (pl.small) return p3d_launch_convsm(a, pl.small, s);
-    if (a.eb.mode && !p3d_igemm2_eb_ok(a, pl)) return hipErrorInvalidValue;
     if (p3d_igemm2_tail_split(a, pl)) return p3d_launch_igemm2_group(&a, 1, pl, s);      // full rounds + a K-sliced tail class
     if (pl.bm == 128 && pl.bn == 128) return launch_t<128, 128>(a, pl, s);
     if (pl.bm == 128 && pl.bn == 64) return launch_t<128, 64>(a, pl, s);
@@ -1067,7 +1010,7 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStr
 
 // ---- grouped launch of residue classes ---------------------------------------------------------------------------------
 bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& pl) {
-    if (n < 2 || n > P3D_IGEMM_CLASSES || pl.small) return false;
+    if (n < 2 || n > P3D_IGEMM_CLASSES) return false;
     for (int i = 0; i < n; ++i) {
         const IgemmArgs& a = v[i];
         // shared: the gathered operand and every extent / stride; per class: grid, offsets, taps, weights, bias, output, statistics
@@ -1123,25 +1066,8 @@ hipError_t launch_group_t(IgemmGroupArgs& g, const long long* tiles, hipStream_t
 }  // namespace
 
 
-// May this launch normalise its own output (BnEpi)?  Every output tile's last arriver waits for the other row tiles of its
-// column range while holding a CU slot: all of them must be able to sit on the chip beside the blocks still to run.
-bool p3d_igemm2_eb_ok(const IgemmArgs& a, const P3dIgemmPlan& pl) {
-    if (pl.small || pl.bm != 64 || pl.bn != 64 || a.accum || a.ngate || a.at_mode == P3D_AT_GRAD) return false;
-    const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
-    const long long mt = (M + 63) / 64, tiles = mt * ((a.Nc + 63) / 64);
-    if (mt > P3D_EB_MAX_MTILES || tiles > P3D_EB_MAX_TILES) return false;
-    if (a.eb.mode < 0 || a.eb.mode > 3) return false;
-    if (a.eb.mode) {
-        if (!a.eb.z || (a.eb.ldz & 3) || !a.eb.gamma || !a.eb.beta || !a.eb.scale || !a.eb.shift || !a.eb.mean || !a.eb.invstd) return false;
-        if (a.eb.mode >= 2 && (!a.eb.r || (a.eb.ldr & 3))) return false;
-        if (a.eb.update_moving && (!a.eb.moving_mean || !a.eb.moving_var)) return false;
-    }
-    return !p3d_igemm2_tail_split(a, pl);
-}
-
 // Would the tail of this single launch be cut into K-slices (then it goes out through the grouped kernel)?
 bool p3d_igemm2_tail_split(const IgemmArgs& a, const P3dIgemmPlan& pl) {
-    if (pl.small) return false;
     if (a.at_mode || a.ngate || pl.splits > 1 || !tail_split_enabled()) return false;
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const long long tiles = ((M + pl.bm - 1) / pl.bm) * ((a.Nc + pl.bn - 1) / pl.bn);

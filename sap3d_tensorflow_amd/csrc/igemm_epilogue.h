@@ -1,6 +1,6 @@
-// Epilogue shared by the convolution kernels (conv_igemm2.hip, conv_small.hip): a finished output tile sits in LDS
+// Epilogue of the convolution kernels (conv_igemm2.hip): a finished output tile sits in LDS
 // (`tile`, row stride BN + 4 floats); this writes it out row-wise as float4 -- bias, optional accumulate, BatchNorm
-// statistics partials, the gated form of the fused-BatchNorm input gradients (BnGate) and the epilogue BatchNorm (BnEpi).
+// statistics partials and the gated form of the fused-BatchNorm input gradients (BnGate).
 // Every sum is folded in a fixed order: results are bit-reproducible.
 #pragma once
 #include "p3d_kernels.h"
@@ -119,7 +119,7 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmArgs& p, const Ge
 
     // -- output rows: bias, optional accumulate, row-wise float4 stores; the stored values go back to the tile for the
     //    statistics pass --------------------------------------------------------------------------------------------
-    const bool want_stats = geo.statpart != nullptr || p.eb.mode != 0;
+    const bool want_stats = geo.statpart != nullptr;
 #pragma unroll 4
     for (int i = tid; i < BM * F4R; i += 256) {
         const int r = i / F4R, c4 = (i - r * F4R) * 4;
@@ -148,92 +148,8 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmArgs& p, const Ge
             float t1 = sred[tid * 2], t2 = sred[tid * 2 + 1];
 #pragma unroll
             for (int g = 1; g < RG; ++g) { t1 += sred[(g * BN + tid) * 2]; t2 += sred[(g * BN + tid) * 2 + 1]; }
-            if (geo.statpart) {
-                float* dst = geo.statpart + ((size_t)(geo.stat_base + mt) * p.Nc + n0 + tid) * 2;
-                dst[0] = t1; dst[1] = t2;
-            }
-            if (p.eb.mode) {
-                // publish: one 8-byte {value, epoch} granule per statistic, write-through, no flag and no drain -- whoever
-                // sweeps sees either the previous launch's tag or this value
-                unsigned long long* g = p.eb.xch + ((size_t)mt * p.Nc + n0 + tid) * 2;
-                const unsigned long long tag = (unsigned long long)p.eb.epoch << 32;
-                __hip_atomic_store(g, tag | __float_as_uint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g + 1, tag | __float_as_uint(t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    if (p.eb.mode) {
-        // ---- BatchNorm of this conv's output, here (BnEpi, p3d_kernels.h): sweep the granules of every row tile of this
-        //      column range, fold in tile order (double), normalise the tile in LDS, store z ------------------------------
-        const int mtiles = (int)((M + BM - 1) / BM);
-        double* dsum = reinterpret_cast<double*>(sred);          // [2][BN] column totals   (sred is free again after the barrier below)
-        float* coef = sred + 4 * BN;                             // [2][BN] scale, shift
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int c = tid % BN, st = tid / BN;
-            double tot = 0.0;
-            if (n0 + c < p.Nc) {
-                const unsigned long long* g = p.eb.xch + ((size_t)(n0 + c)) * 2 + st;
-                const size_t stride = (size_t)p.Nc * 2;
-                unsigned long long v[P3D_EB_MAX_MTILES];
-                // a sweep is one round trip to the coherent level (~1 us): the bound is a sweep count, not a clock read (a
-                // clock read is a scalar memory operation of its own and would double every round)
-                bool ok = false;
-                for (int sweep = 0; sweep < (1 << 21); ++sweep) {
-#pragma unroll
-                    for (int q = 0; q < P3D_EB_MAX_MTILES; ++q)
-                        v[q] = __hip_atomic_load(g + (size_t)min(q, mtiles - 1) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = true;
-#pragma unroll
-                    for (int q = 0; q < P3D_EB_MAX_MTILES; ++q) ok = ok && (unsigned)(v[q] >> 32) == p.eb.epoch;
-                    if (ok) break;
-                }
-                if (!ok) atomicOr(p.eb.err, 1u);          // ~2 s of sweeps: give up, loudly (p3d_eb_timeouts)
-#pragma unroll
-                for (int q = 0; q < P3D_EB_MAX_MTILES; ++q)
-                    if (q < mtiles) tot += (double)__uint_as_float((unsigned)v[q]);
-            }
-            dsum[st * BN + c] = tot;
-        }
-        __syncthreads();
-        if (tid < BN && (n0 + tid) < p.Nc) {
-            const int k = n0 + tid;
-            const double mean = dsum[tid] * p.eb.inv_m;
-            double var = dsum[BN + tid] * p.eb.inv_m - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float meanf = (float)mean, varf = (float)var;
-            const float inv = 1.0f / sqrtf(varf + p.eb.eps);
-            const float sc = p.eb.gamma[k] * inv;
-            const float sh = p.eb.beta[k] - meanf * sc;
-            coef[tid] = sc; coef[BN + tid] = sh;
-            if (mt == 0) {          // one publisher per column range; every block of the range holds the same bits
-                p.eb.scale[k] = sc; p.eb.shift[k] = sh; p.eb.mean[k] = meanf; p.eb.invstd[k] = inv;
-                if (p.eb.update_moving) {      // moving -= (moving - batch) * (1 - 0.99)   (biased variance)
-                    p.eb.moving_mean[k] -= (p.eb.moving_mean[k] - meanf) * (1.0f - 0.99f);
-                    p.eb.moving_var[k] -= (p.eb.moving_var[k] - varf) * (1.0f - 0.99f);
-                }
-            }
-        }
-        __syncthreads();
-        const int ebm = p.eb.mode;
-#pragma unroll 4
-        for (int i = tid; i < BM * F4R; i += 256) {
-            const int r = i / F4R, c4 = (i - r * F4R) * 4;
-            const int ro = rowIdx[r];
-            const int col = n0 + c4;
-            if (ro < 0 || col >= p.Nc) continue;
-            const float4 v = *reinterpret_cast<const float4*>(tile + r * LDT + c4);
-            const float4 sc = *reinterpret_cast<const float4*>(coef + c4), sh = *reinterpret_cast<const float4*>(coef + BN + c4);
-            float4 u = make_float4(fmaf(sc.x, v.x, sh.x), fmaf(sc.y, v.y, sh.y), fmaf(sc.z, v.z, sh.z), fmaf(sc.w, v.w, sh.w));
-            float4 z;
-            if (ebm == 1) {
-                z = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
-            } else {
-                const float4 rr = *reinterpret_cast<const float4*>(p.eb.r + (long long)ro * p.eb.ldr + col);
-                if (ebm == 2) z = make_float4(fmaxf(u.x + rr.x, 0.f), fmaxf(u.y + rr.y, 0.f), fmaxf(u.z + rr.z, 0.f), fmaxf(u.w + rr.w, 0.f));
-                else z = make_float4(rr.x + fmaxf(u.x, 0.f), rr.y + fmaxf(u.y, 0.f), rr.z + fmaxf(u.z, 0.f), rr.w + fmaxf(u.w, 0.f));
-            }
-            *reinterpret_cast<float4*>(p.eb.z + (long long)ro * p.eb.ldz + col) = z;
+            float* dst = geo.statpart + ((size_t)(geo.stat_base + mt) * p.Nc + n0 + tid) * 2;
+            dst[0] = t1; dst[1] = t2;
         }
     }
 }

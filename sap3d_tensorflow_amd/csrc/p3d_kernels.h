@@ -74,6 +74,12 @@ __device__ __forceinline__ void p3d_warm_kernarg_lines() {
     if constexpr (LINES >= 17)
         asm volatile(P3D_WL4(0x0, 0x40, 0x80, 0xc0) P3D_WL4(0x100, 0x140, 0x180, 0x1c0) P3D_WL4(0x200, 0x240, 0x280, 0x2c0)
                      P3D_WL4(0x300, 0x340, 0x380, 0x3c0) P3D_WL(0x400) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(ka) : "memory");
+    else if constexpr (LINES >= 14)
+        asm volatile(P3D_WL4(0x0, 0x40, 0x80, 0xc0) P3D_WL4(0x100, 0x140, 0x180, 0x1c0) P3D_WL4(0x200, 0x240, 0x280, 0x2c0)
+                     P3D_WL(0x300) P3D_WL(0x340) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(ka) : "memory");
+    else if constexpr (LINES >= 11)
+        asm volatile(P3D_WL4(0x0, 0x40, 0x80, 0xc0) P3D_WL4(0x100, 0x140, 0x180, 0x1c0) P3D_WL(0x200) P3D_WL(0x240) P3D_WL(0x280)
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(ka) : "memory");
     else if constexpr (LINES >= 8)
         asm volatile(P3D_WL4(0x0, 0x40, 0x80, 0xc0) P3D_WL4(0x100, 0x140, 0x180, 0x1c0) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(ka) : "memory");
     else if constexpr (LINES >= 6)
@@ -123,33 +129,10 @@ struct BnGate {            // epilogue of an input-gradient launch: g = (scale*y
     float* out; int ldo;                         // gated gradient
     float* part;                                 // [m tiles][Nc][2]  (sum g, sum g*xhat) per output-tile row, plain stores
 };
-// ---- BatchNorm in the PRODUCING conv's epilogue (round 4; small tensors: every output tile of the launch is resident at once).
-// The block that holds a finished output tile (the last arriver of its K-slices) publishes the tile's per-channel (sum, sumsq)
-// as 8-byte {value, epoch} granules with ONE write-through store each, sweeps the granules of the other row tiles of its
-// column range (agent-scope loads, no flag, no fence: the epoch tag says "this launch's value"), folds them in tile order in
-// double -- every block of a column range computes the same bits -- and applies scale / shift (+ ReLU, + residual) to the
-// tile it still holds in LDS: y (raw) and z (normalised) leave in one launch, the BatchNorm pass of its own is gone.
-// Waiting blocks hold their CU slot, so the launcher only takes this path when tiles <= P3D_EB_MAX_TILES (every tile's
-// last arriver can be resident beside the blocks still to run); spins are bounded by wall time and report through `err`.
-#define P3D_EB_MAX_MTILES 16
-#define P3D_EB_MAX_TILES 224
-struct BnEpi {
-    int mode;                    // 0: off.  1: z = relu(bn(y))   2: z = relu(bn(y) + r)   3: z = r + relu(bn(y))   (bn_apply modes 0, 1, 4)
-    float* z; int ldz;
-    const float* r; int ldr;     // residual / skip operand on the output lattice
-    const float* gamma; const float* beta;
-    float* scale; float* shift; float* mean; float* invstd;     // published by the row-tile-0 block of every column range
-    float* moving_mean; float* moving_var; int update_moving;
-    unsigned long long* xch;     // [m tiles][Nc][2] granules (filled by the launcher)
-    unsigned epoch;              // tag of this launch (filled by the launcher)
-    unsigned* err;               // device word: set when a sweep gave up (filled by the launcher)
-    double inv_m; float eps;
-};
 enum { P3D_AT_NONE = 0, P3D_AT_RELU1 = 1, P3D_AT_RELU2 = 2, P3D_AT_GRAD = 3 };
 //  RELU1: a = relu(s1*x + t1)                           RELU2: a = relu(s1*x + t1) + relu(s2*x2 + t2)   (ST_B / ST_C sums)
 //  GRAD : a = k1*x + k2*x2 + k3   (x = gated gradient, x2 = BN input); padded taps stay 0
 
-struct P3dIgemmPlan;
 // Implicit-GEMM convolution launch:  Y[m, n] (+)= sum_taps sum_k A[m+tap, k] * B_tap[k, n] (+ bias[n])
 struct IgemmArgs {
     const float* x;       // gathered operand (already offset to its channel slice)
@@ -189,7 +172,6 @@ struct IgemmArgs {
     // (after bias / accumulate) goes raw to y when raw_store, and gated to gate[q].out; ngate = 0: plain store to y
     int ngate, raw_store;
     BnGate gate[2];
-    BnEpi eb;             // BatchNorm in this launch's own epilogue (single-class launches of 64x64 tiles)
     int ntaps;
     P3dTap taps[P3D_MAX_TAPS];
 };
@@ -221,7 +203,6 @@ struct IgemmGroupArgs {
 // Tile and split-K choice of the pipelined kernel (conv_igemm2.hip)
 struct P3dIgemmPlan {
     int bm = 64, bn = 64, splits = 1;
-    int small = 0;        // > 0: the small-M kernel (conv_small.hip) in this wave arrangement; bm / bn are its tile
     const char* name = "";
 };
 // number of output-tile rows (= statistics partials) a launch with this plan produces
@@ -232,10 +213,6 @@ inline int p3d_igemm2_mtiles(const IgemmArgs& a, const P3dIgemmPlan& pl) {
 // Per-stream scratch for K-sliced launches (partial tiles + arrival counters).  Launches on one stream run in order, so
 // they share it; the buffers only grow, and an outgrown buffer stays allocated (captured graphs may still name it).
 hipError_t p3d_stream_scratch(hipStream_t s, size_t slab_floats, size_t counters, float** slab, unsigned** cnt);
-// granule scratch of the epilogue BatchNorm for the next launch on stream s (+ that launch's epoch tag and the give-up word)
-hipError_t p3d_stream_xch(hipStream_t s, size_t granules, unsigned long long** xch, unsigned* epoch, unsigned** err);
-bool p3d_igemm2_eb_ok(const IgemmArgs& a, const struct P3dIgemmPlan& pl);      // may this launch carry a.eb?  (tile shape, tile counts)
-long long p3d_eb_timeouts();                 // sweeps that gave up so far (synchronises; must be 0), -1 on a HIP error
 long long p3d_scratch_dirty_counters();      // test hook: non-zero arrival counters with nothing in flight (must be 0)
 void p3d_release_scratch();     // frees every scratch buffer (process shutdown; no launch may be in flight)
 
@@ -280,10 +257,7 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a, const P3dIgemmPlan& plan, hipSt
 bool p3d_igemm2_tail_split(const IgemmArgs& a, const P3dIgemmPlan& pl);      // a single launch whose last round gets K-sliced (goes out grouped)
 bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& plan);
 hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan& plan, hipStream_t s);
-// the small-M kernel (conv_small.hip): wave arrangement for this launch (0: not its case) and the launch itself
-int p3d_convsm_shape(const IgemmArgs& a);
-hipError_t p3d_launch_convsm(const IgemmArgs& a, int shape, hipStream_t s);
-void p3d_igemm2_override(int tile, int splits);   // test / tools hook: force the tile (0: 64x64, 1: 128x64, 2: 128x128 of the pipelined kernel -- the small-M kernel is then off) and the K-slice count; -1 / 0 = no override
+void p3d_igemm2_override(int tile, int splits);   // test / tools hook: force the tile (0: 64x64, 1: 128x64, 2: 128x128) and the K-slice count; -1 / 0 = no override
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s);   // up to P3D_WGRAD_GROUP problems, one launch
 const char* p3d_wgrad2_variant(const WgradArgs& a);
