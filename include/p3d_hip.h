@@ -132,6 +132,18 @@ int p3d_set_adam(p3d_handle* h, float lr, float beta1, float beta2, float eps);
 int p3d_activation_info(p3d_handle* h, const char* name, int64_t shape[5]);
 int p3d_get_activation(p3d_handle* h, const char* name, float* host, int64_t count);
 
+/* ---- decisions of the last forward (TEST HOOK, tests/test_gpu_pinned.py): the ReLU gates and max-pool choices the backward pass of
+ *      this handle will use -- so that the oracle can differentiate the SAME piecewise-linear branch (a float32 forward takes
+ *      a handful of near-zero decisions differently from a float64 one, and each moves a gradient tensor by per cent).
+ *      Site `index` (0 .. count-1, graph order) is a normalise / ReLU pass ("bn": out1 / out2 are NON-ZERO where the gate of the
+ *      first / second BatchNorm branch -- TF scopes name1 / name2, name2 empty when there is one -- is open; produced by the
+ *      pass's own backward kernel on a gradient of ones with the statistics terms off) or a max-pool ("pool": out1 is the pool's
+ *      input as this handle holds it; its arg-max follows from it exactly).  count = elements of `shape`.  Call after a forward
+ *      or backward pass of the whole graph with BatchNorm fusion off; synchronises. */
+int p3d_debug_decision_count(p3d_handle* h);
+int p3d_debug_decision_info(p3d_handle* h, int index, const char** kind, const char** name1, const char** name2, int64_t shape[5]);
+int p3d_debug_decision_get(p3d_handle* h, int index, float* out1, float* out2, int64_t count);
+
 /* ---- one bottleneck in isolation (BASELINE.json configs[0], SURVEY.md 8d cfg 1 "standalone variant"): the forward of
  *      Bottleneck(...).infer() (p3d.py:83-136; gn/p3d_gn.py:127-179 for the GN structures) number `block_id`
  *      (0 .. sum(blocks)-1) of this handle's graph on a caller-supplied input, with the handle's current parameters.

@@ -27,13 +27,15 @@ import numpy as np
 # tape
 # ----------------------------------------------------------------------------
 class Var:
-    """A value on the tape.  `grad` is filled by Tape.backward()."""
-    __slots__ = ("data", "grad", "name")
+    """A value on the tape.  `grad` is filled by Tape.backward().  `tag` names the normalisation layer a value came out of
+    (its TF scope): relu() looks a pinned decision mask up by it (Tape.pins)."""
+    __slots__ = ("data", "grad", "name", "tag")
 
     def __init__(self, data, name=None):
         self.data = data
         self.grad = None
         self.name = name
+        self.tag = None
 
     @property
     def shape(self):
@@ -45,10 +47,17 @@ class Var:
 
 
 class Tape:
+    """pins: decisions taken from ANOTHER evaluation of the same graph (tests/: the HIP forward's), so that the gradient of
+    this evaluation is the gradient of the same piecewise-linear branch.  {'relu': {norm scope: bool array}, 'pool':
+    [input arrays]} -- a relu whose argument carries a pinned tag takes that mask (forward and backward) instead of
+    x > 0; a max-pool picks its arg-max on the pinned input that matches its own (same shape, closest).  pin_log counts
+    what was used and how many decisions differed from this evaluation's own."""
     def __init__(self):
         self.ops = []          # backward closures, forward order
         self.updates = []      # (array_to_update, new_value): BN moving stats (UPDATE_OPS)
         self.taps = {}         # name -> Var, activation taps for parity tests
+        self.pins = None
+        self.pin_log = {"relu": 0, "relu_flips": 0, "pool": 0, "pool_flips": 0, "elements": 0}
 
     def record(self, fn):
         self.ops.append(fn)
@@ -266,18 +275,31 @@ def group_norm(tape, x, gamma, beta, G=32, eps=1e-5):
 
 
 def relu(tape, x):
-    """tf.nn.relu; gradient is dy where y > 0 (zero at 0)."""
-    out = Var(np.maximum(x.data, 0))
+    """tf.nn.relu; gradient is dy where y > 0 (zero at 0).  With a pinned mask for x's tag (Tape.pins) the mask decides."""
+    pin = None
+    if tape.pins is not None and x.tag is not None:
+        pin = tape.pins.get("relu", {}).get(x.tag)
+    if pin is not None:
+        mask = np.asarray(pin).reshape(x.data.shape).astype(bool)
+        own = x.data > 0
+        tape.pin_log["relu"] += 1
+        tape.pin_log["relu_flips"] += int((own != mask).sum())
+        tape.pin_log["elements"] += mask.size
+        out = Var(np.where(mask, x.data, 0).astype(x.data.dtype))
+    else:
+        mask = None
+        out = Var(np.maximum(x.data, 0))
 
     def bwd():
         if out.grad is not None:
-            x.acc(out.grad * (out.data > 0))
+            x.acc(out.grad * (out.data > 0 if mask is None else mask))
     tape.record(bwd)
     return out
 
 
 def add(tape, a, b):
     out = Var(a.data + b.data)
+    out.tag = a.tag if a.tag is not None else b.tag      # relu(bn(y) + r): the sum is gated under the BatchNorm's name
 
     def bwd():
         if out.grad is not None:
@@ -341,13 +363,32 @@ def max_pool3d(tape, x, ksize, strides):
     xd = x.data
     N, D, H, W, C = xd.shape
     (Do, Ho, Wo), taps = _conv_taps(xd.shape, tuple(ksize) + (C, C), strides)
-    y = np.full((N, Do, Ho, Wo, C), -np.inf, dtype=xd.dtype)
-    idx = np.full((N, Do, Ho, Wo, C), -1, dtype=np.int16)
-    for t, (_, osl, isl) in enumerate(taps):
-        v = xd[isl]
-        better = v > y[osl]
-        y[osl] = np.where(better, v, y[osl])
-        idx[osl] = np.where(better, t, idx[osl])
+
+    def arg_max(src):
+        best = np.full((N, Do, Ho, Wo, C), -np.inf, dtype=src.dtype)
+        which = np.full((N, Do, Ho, Wo, C), -1, dtype=np.int16)
+        for t, (_, osl, isl) in enumerate(taps):
+            v = src[isl]
+            better = v > best[osl]
+            best[osl] = np.where(better, v, best[osl])
+            which[osl] = np.where(better, t, which[osl])
+        return best, which
+
+    y, idx = arg_max(xd)
+    if tape.pins is not None and tape.pins.get("pool"):
+        # the pinned evaluation's input of THIS pool: same shape, closest values (it is the same tensor up to rounding)
+        cands = [p for p in tape.pins["pool"] if tuple(p.shape) == tuple(xd.shape)]
+        scale = max(float(np.abs(xd).max()), 1e-30)
+        dist = [float(np.abs(p.astype(np.float64) - xd).max()) / scale for p in cands]
+        if not cands or min(dist) > tape.pins.get("pool_tol", 1e-3):
+            raise ValueError("no pinned max-pool input matches this pool's input %s (distances %s)" % (xd.shape, dist))
+        _, pinned = arg_max(cands[int(np.argmin(dist))])
+        tape.pin_log["pool"] += 1
+        tape.pin_log["pool_flips"] += int((pinned != idx).sum())
+        idx = pinned
+        y = np.zeros((N, Do, Ho, Wo, C), dtype=xd.dtype)
+        for t, (_, osl, isl) in enumerate(taps):
+            y[osl] = np.where(idx[osl] == t, xd[isl], y[osl])
     out = Var(y)
 
     def bwd():

@@ -113,7 +113,9 @@ def batch_normalization(g, x, training, name=None):
     beta = g.variable(scope + '/beta', (C,), g.zeros)
     mm = g.state(scope + '/moving_mean', (C,), 0.0)
     mv = g.state(scope + '/moving_variance', (C,), 1.0)
-    return nn.batch_normalization(g.tape, x, gamma, beta, mm, mv, training)
+    out = nn.batch_normalization(g.tape, x, gamma, beta, mm, mv, training)
+    out.tag = scope              # relu() finds a pinned decision mask under this name (nn.Tape.pins)
+    return out
 
 
 def layers_conv3d(g, x, filters, kernel, strides, name=None):
@@ -496,10 +498,12 @@ def forward(params, x, dropout=0.0, training=False, structure='unet', cfg=None, 
 
 
 def loss_and_grads(params, x, y, dropout=0.0, training=True, structure='unet', cfg=None, dtype=np.float32,
-                   keep_mask=None):
+                   keep_mask=None, pins=None):
     """Forward + Smooth-L1-sum loss (train.py:156-159) + backward.  Returns
-    (loss, pred, grads{name->array}, graph).  keep_mask: the dropout keep pattern when dropout > 0."""
+    (loss, pred, grads{name->array}, graph).  keep_mask: the dropout keep pattern when dropout > 0.
+    pins: ReLU / max-pool decisions of another evaluation of this graph (nn.Tape.pins)."""
     g = Graph(params, dtype=dtype, create=False)
+    g.tape.pins = pins
     X = nn.Var(x.astype(dtype))
     pred = STRUCTURES[structure](g, X, dropout, x.shape[0], training, cfg, keep_mask)
     pred_reshape = nn.reshape(g.tape, pred, y.shape)

@@ -23,6 +23,7 @@ __device__ __forceinline__ void merge(float& s, float& m, float& t, float s2, fl
 
 // grid (chunks, N); thread = channel (strided if C > 256); rows of the chunk are walked serially (coalesced over c)
 __global__ __launch_bounds__(256) void chan_pool_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     const int R = a.D * a.H * a.W;
     const int n = blockIdx.y, ch = blockIdx.x;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(CbamArgs a) {
 // the C inputs), slices folded through LDS.  The old one-block-per-sample version walked 512 dependent loads per
 // thread and cost 180 us per site.
 __global__ __launch_bounds__(256) void chan_hidden_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     extern __shared__ float sm[];                  // avg[C] max[C] part[32][8][2]
     float* avg = sm; float* mx = sm + a.C; float* part = mx + a.C;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256) void chan_hidden_kernel(CbamArgs a) {
 
 // Output layer + sigmoid.  grid (ceil(C/256), N), thread = channel; k1 rows are read coalesced over c.
 __global__ __launch_bounds__(256) void chan_out_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     extern __shared__ float h[];                   // [Ch] = havg + hmax (the MLP is shared, so its outputs add)
     const int n = blockIdx.y;
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void chan_out_kernel(CbamArgs a) {
 
 // wave per position: channel mean / max of f = x * cs
 __global__ __launch_bounds__(256) void spat_pool_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     const int R = a.D * a.H * a.W;
     const long long M = (long long)a.N * R;
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256) void spat_pool_kernel(CbamArgs a) {
 // eight lanes per position (lane k < 7 takes the kernel plane kd = k; the stage-3 maps have 784 positions, a thread per
 // position left the chip to four blocks): 7x7x7 SAME conv over the 2-channel map, planes folded by a fixed shuffle tree, sigmoid
 __global__ __launch_bounds__(256) void spat_conv_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     __shared__ float kw[686];
     for (int i = threadIdx.x; i < 686; i += blockDim.x) kw[i] = a.k7[i];
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(256) void spat_conv_kernel(CbamArgs a) {
 // ---- backward ---------------------------------------------------------------------------------------------
 // wave per position: dss = sum_c dout*f ; dpre = dss * ss * (1 - ss)
 __global__ __launch_bounds__(256) void bwd_dpre_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     const int R = a.D * a.H * a.W;
     const long long M = (long long)a.N * R;
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(256) void bwd_dpre_kernel(CbamArgs a) {
 // eight lanes per position (lane k < 7: kernel plane kd = k): dsp[pos][ch] = sum_taps dpre[pos - tap + 3] * K[tap][ch]
 // (transpose of the SAME conv), planes folded by a fixed shuffle tree
 __global__ __launch_bounds__(256) void bwd_spat_conv_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     __shared__ float kw[686];
     for (int i = threadIdx.x; i < 686; i += blockDim.x) kw[i] = a.k7[i];
@@ -237,6 +244,7 @@ __global__ __launch_bounds__(256) void bwd_spat_conv_kernel(CbamArgs a) {
 // dK7[tap][ch] = sum_pos sp[pos + tap - 3][ch] * dpre[pos].  Block = a chunk of 64 positions (coordinates and dpre
 // staged in LDS once), thread = one tap (343 of 384 threads); one atomic pair per (block, tap).
 __global__ __launch_bounds__(384) void bwd_k7_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     __shared__ int pd[64], ph[64], pw[64], pn[64];
     __shared__ float pg[64];
@@ -298,6 +306,7 @@ __global__ __launch_bounds__(384) void bwd_k7_kernel(CbamArgs a) {
 // grid (chunks, N), wave per position inside the chunk: df = dout*ss + dmean/C + dmax*[f == max]/ties;
 // dx (+)= df*cs ; per-(n,c) partial of dcs = sum_pos df*x kept in registers, folded through LDS.
 __global__ __launch_bounds__(256) void bwd_df_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     extern __shared__ float red[];                 // [4][C]
     const int R = a.D * a.H * a.W;
@@ -355,6 +364,7 @@ __global__ __launch_bounds__(256) void bwd_df_kernel(CbamArgs a) {
 // publishes it in a.dO), then 8 hidden units per block: 32 lanes per unit walk the k1 row coalesced and fold by
 // shuffles.  dh [n][2][Ch] = gradients of the hidden activations of the avg / max branch.
 __global__ __launch_bounds__(256) void bwd_mlp1_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     extern __shared__ float dO[];                  // [C]
     const int n = blockIdx.y, j0 = blockIdx.x * 8;
@@ -385,6 +395,7 @@ __global__ __launch_bounds__(256) void bwd_mlp1_kernel(CbamArgs a) {
 // MLP backward, step 2a -- thread per (n, c): gradients of the pooled vectors; block 0 also folds db0, and the
 // threads of sample 0 fold db1.
 __global__ __launch_bounds__(256) void bwd_mlp2a_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.N * a.C) {
@@ -426,6 +437,7 @@ __global__ __launch_bounds__(256) void bwd_mlp2a_kernel(CbamArgs a) {
 }
 // step 2b -- thread per weight element (c, j): dk0[c][j], dk1[j][c] (each owned by one thread: plain RMW)
 __global__ __launch_bounds__(256) void bwd_mlp2b_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.C * a.Ch) return;
@@ -442,6 +454,7 @@ __global__ __launch_bounds__(256) void bwd_mlp2b_kernel(CbamArgs a) {
 
 // dx += davg/R + dmax * [x == max over the sample's rows] / ties
 __global__ __launch_bounds__(256) void bwd_chan_kernel(CbamArgs a) {
+    p3d_warm_kernargs<CbamArgs>();
     P3D_CHAIN_PRIO();
     const int R = a.D * a.H * a.W, c4n = a.C >> 2;
     const long long total = (long long)a.N * R * c4n;

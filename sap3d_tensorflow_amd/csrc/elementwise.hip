@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int ld, l
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
+    p3d_warm_kernarg_lines<(int)(sizeof(BnApplyArgs) / 64)>();
     P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = a.M * c4n;
@@ -186,6 +187,7 @@ __device__ __forceinline__ void bn_fold64(const BnParams& bn, int c0, double inv
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_fold_apply_kernel(BnApplyArgs a, BnParams bn1, BnParams bn2, double invM, int batch1, int batch2,
                                                            int update_moving, float eps, int rows_per_block) {
+    p3d_warm_kernarg_lines<(int)((sizeof(BnApplyArgs) + 2 * sizeof(BnParams)) / 64)>();
     P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 2 || MODE == 3);
     __shared__ __attribute__((aligned(16))) float sc1[64], sh1[64], sc2[64], sh2[64];
@@ -237,6 +239,7 @@ __device__ __forceinline__ void bn_bwd_gates(const BnBwdArgs& a, long long row, 
 // Per-channel sums of g and g*xhat.  Thread = one float4 channel group, RPI rows per block pass.
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+    p3d_warm_kernarg_lines<(int)(sizeof(BnBwdArgs) / 64)>();
     P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 2 || MODE == 3);
     __shared__ float red[256][TWO ? 16 : 8];
@@ -294,6 +297,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 // 6-8 dependent batches of loads -- this kernel sits between the reduce and the apply pass of every large BatchNorm backward).
 template <int LPC>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int two) {
+    p3d_warm_kernarg_lines<(int)(sizeof(BnBwdArgs) / 64)>();
     P3D_CHAIN_PRIO();
     const int r = threadIdx.x % LPC;
     const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
@@ -359,6 +363,7 @@ __device__ __forceinline__ void ldcoef(const float* coef, int c, float4& c1, flo
 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+    p3d_warm_kernarg_lines<(int)(sizeof(BnBwdArgs) / 64)>();
     P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 2 || MODE == 3);
     const int c4n = a.C >> 2;
@@ -402,6 +407,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolArgs a) {
+    p3d_warm_kernarg_lines<(int)(sizeof(PoolArgs) / 64)>();
     P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * c4n;
@@ -757,6 +763,7 @@ hipError_t p3d_maxpool_fwd(const PoolArgs& a, hipStream_t s) {
 // Non-overlapping windows (k == s, no padding: the temporal pools p3d.py:183,189,195): every input cell belongs to
 // exactly one window, so dx is written (or accumulated) directly -- no atomics, no zero fill.
 __global__ __launch_bounds__(256) void maxpool_bwd_disjoint_kernel(PoolArgs a, int accumulate) {
+    p3d_warm_kernarg_lines<(int)(sizeof(PoolArgs) / 64)>();
     P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = (long long)a.N * a.Do * a.Ho * a.Wo * c4n;
@@ -791,6 +798,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_disjoint_kernel(PoolArgs a, i
 // Overlapping windows (pool1, p3d.py:177: k = [2,3,3], s = 2): thread = one input cell x 4 channels; it visits the
 // windows that contain the cell (at most ceil(k/s) per axis) and takes dy where the stored arg-max tap is its own.
 __global__ __launch_bounds__(256) void maxpool_bwd_gather_kernel(PoolArgs a, int accumulate) {
+    p3d_warm_kernarg_lines<(int)(sizeof(PoolArgs) / 64)>();
     P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = (long long)a.N * a.Di * a.Hi * a.Wi * c4n;

@@ -122,6 +122,7 @@ __global__ void gn_finalize_kernel(GnParams p, int N, int R, float eps) {
 // ---- apply
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
+    p3d_warm_kernargs<GnApplyArgs>();
     P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = a.M * c4n;
@@ -170,6 +171,7 @@ __device__ __forceinline__ void gn_gates(const GnApplyArgs& a, long long row, in
 // per-(n,c) sums of g and g*xhat over a slice of the sample's rows.  grid = (row slices, N)
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnApplyArgs a) {
+    p3d_warm_kernargs<GnApplyArgs>();
     P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 3);
     __shared__ float red[256][TWO ? 16 : 8];
@@ -290,6 +292,7 @@ __device__ __forceinline__ float4 gn_dx(const GnParams& g, long long t, float4 g
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnApplyArgs a) {
+    p3d_warm_kernargs<GnApplyArgs>();
     P3D_CHAIN_PRIO();
     const int c4n = a.C >> 2;
     const long long total = a.M * c4n;
@@ -329,6 +332,7 @@ __device__ __forceinline__ float hsum4(float4 v) { return (v.x + v.y) + (v.z + v
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_small_fwd_kernel(GnApplyArgs a) {
+    p3d_warm_kernargs<GnApplyArgs>();
     P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 3);
     __shared__ float xch[4];
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd_kernel(GnApplyArgs a) {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GnApplyArgs a) {
+    p3d_warm_kernargs<GnApplyArgs>();
     P3D_CHAIN_PRIO();
     constexpr bool TWO = (MODE == 3);
     __shared__ float4 red[256][TWO ? 4 : 2];

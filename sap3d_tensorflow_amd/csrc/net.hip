@@ -312,6 +312,13 @@ struct Op {
     double bflops = 0, bbytes = 0;          // backward algorithmic work
     std::vector<struct Param*> owns;        // trainable variables whose gradients this op's backward produces
     std::function<void(const Ctx&)> fwd, bwd;
+    // Decisions of the last forward, for the decision-pinned parity tests (p3d_debug_decision_*): a normalise / ReLU pass runs
+    // its OWN backward kernel on dz = 1 with the statistics terms off (the inference form dy = gamma*invstd * gate), so what
+    // comes out is non-zero exactly where the gate of the real backward is open; a max-pool hands out its input.
+    std::string dec_kind;                   // "" (none), "bn", "pool"
+    std::string dec_name1, dec_name2;       // bn: TF scopes of the one or two BatchNorms
+    const struct Act* dec_act = nullptr;    // bn: shape of the gated tensor; pool: the pool's input
+    std::function<void(hipStream_t, const float* ones, float* o1, float* o2, float* scratch)> gates;
 };
 
 struct ConvGeo {       // a SAME forward conv: input extents -> output extents
@@ -1225,6 +1232,36 @@ struct p3d_handle {
             if (two) fin(bn2);
             launch(c, kn_apply.c_str(), 0, tens * (y2 ? 3 : 2), [&]() { return p3d_bn_apply(a, c.s); });
         };
+        {
+            auto scope = [](const BN* bn) { const std::string& n = bn->gamma->name; return n.substr(0, n.rfind('/')); };
+            op.dec_kind = "bn"; op.dec_name1 = scope(bn1); op.dec_name2 = two ? scope(bn2) : std::string(); op.dec_act = y1;
+            op.gates = [=](hipStream_t st, const float* ones, float* o1, float* o2, float* scratch) {
+                if (small) {
+                    BnSmallArgs a;
+                    memset(&a, 0, sizeof(a));
+                    a.mode = mode; a.M = (int)M; a.C = C; a.y1 = y1->p; a.ld1 = y1->ld;
+                    if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; }
+                    a.bn1 = bn_params(bn1);
+                    if (two) a.bn2 = bn_params(bn2);
+                    a.batch1 = 0; a.batch2 = 0; a.eps = 1e-3f;
+                    a.dz = ones; a.lddz = C; a.dy1 = o1; a.lddy1 = C; a.dy2 = o2; a.lddy2 = C; a.acc2 = 0;
+                    a.dgamma1 = scratch; a.dbeta1 = scratch + C; a.dgamma2 = scratch + 2 * C; a.dbeta2 = scratch + 3 * C;
+                    HIPCHECK(p3d_bn_small_bwd(a, st));
+                    return;
+                }
+                BnBwdArgs a;
+                memset(&a, 0, sizeof(a));
+                a.mode = mode; a.M = M; a.C = C; a.dz = ones; a.lddz = C;
+                a.y1 = y1->p; a.ld1 = y1->ld; a.scale1 = bn1->scale; a.shift1 = bn1->shift; a.mean1 = bn1->mean; a.invstd1 = bn1->invstd;
+                a.gamma1 = bn1->gamma->p; a.batch1 = 0; a.dy1 = o1; a.lddy1 = C;
+                if (y2) { a.y2 = y2->p; a.ld2 = y2->ld; a.dy2 = o2; a.lddy2 = C; }
+                if (two) {
+                    a.scale2 = bn2->scale; a.shift2 = bn2->shift; a.mean2 = bn2->mean; a.invstd2 = bn2->invstd;
+                    a.gamma2 = bn2->gamma->p; a.batch2 = 0;
+                }
+                HIPCHECK(p3d_bn_bwd_apply(a, st));       // (dropout sites: the gate alone -- the keep pattern is the tests' own input)
+            };
+        }
         op.bwd = [=](const Ctx& c) {
             if (fused_site && c.fuse_bwd) return;
             if (small) {
@@ -1286,6 +1323,7 @@ struct p3d_handle {
             return a;
         };
         const double pool_bytes = op.bytes;
+        op.dec_kind = "pool"; op.dec_act = x;
         op.fwd = [=](const Ctx& c) { launch(c, "maxpool_fwd_kernel", 0, pool_bytes, [&]() { return p3d_maxpool_fwd(mk(), c.s); }); };
         op.bwd = [=](const Ctx& c) {
             const PoolArgs pa = mk();
@@ -3099,6 +3137,50 @@ struct DevBuf {
 int64_t prod5(const int64_t s[5]) { return s[0] * s[1] * s[2] * s[3] * s[4]; }
 bool is_stem_shape(const int64_t xs[5], const int64_t ws[5]) { return xs[4] % 4 != 0 && ws[0] == 1; }
 }  // namespace
+
+// ---- decisions of the last forward (test hook, include/p3d_hip.h) ---------------------------------------------------------
+static const Op* decision_op(p3d_handle* h, int index) {
+    if (!h) throw P3dError("null handle");
+    int k = 0;
+    for (const Op& op : h->ops)
+        if (!op.dec_kind.empty() && k++ == index) return &op;
+    throw P3dError("no decision site " + std::to_string(index));
+}
+int p3d_debug_decision_count(p3d_handle* h) {
+    if (!h) return -1;
+    int k = 0;
+    for (const Op& op : h->ops) k += !op.dec_kind.empty();
+    return k;
+}
+int p3d_debug_decision_info(p3d_handle* h, int index, const char** kind, const char** name1, const char** name2, int64_t shape[5]) {
+    API_BEGIN
+    const Op* op = decision_op(h, index);
+    if (kind) *kind = op->dec_kind.c_str();
+    if (name1) *name1 = op->dec_name1.c_str();
+    if (name2) *name2 = op->dec_name2.c_str();
+    const Act* a = op->dec_act;
+    if (shape) { shape[0] = a->N; shape[1] = a->D; shape[2] = a->H; shape[3] = a->W; shape[4] = a->C; }
+    API_END
+}
+int p3d_debug_decision_get(p3d_handle* h, int index, float* out1, float* out2, int64_t count) {
+    API_BEGIN
+    const Op* op = decision_op(h, index);
+    const Act* a = op->dec_act;
+    if (!out1 || count != a->rows() * a->C) throw P3dError("decision buffer size mismatch");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (op->dec_kind == "pool") {
+        h->download_act(const_cast<Act*>(a), out1);
+    } else {
+        if (h->last_forward_fused) throw P3dError("decisions are read from the stored tensors: run the forward with BatchNorm fusion off");
+        std::vector<float> ones((size_t)count, 1.0f);
+        DevBuf d1(count, ones.data()), o1(count), o2(count), scratch(4 * (int64_t)a->C + 64);
+        op->gates(h->stream, d1.p, o1.p, o2.p, scratch.p);
+        o1.get(out1, count);
+        if (out2) o2.get(out2, count);
+    }
+    API_END
+}
 
 int p3d_op_conv3d(int device, const float* x, const int64_t xs[5], const float* w, const int64_t ws[5], const int s[3],
                   const float* bias, float* y) {

@@ -174,6 +174,31 @@ class P3DSession:
         check(lib().p3d_block_backward(self._h, int(block_id), fptr(a), a.size, fptr(d), d.size, fptr(din)))
         return din
 
+    def decisions(self):
+        """The ReLU gates and max-pool inputs of the last forward pass, as the backward pass of this session uses them
+        (p3d_debug_decision_*; tests): {'relu': {BatchNorm scope: bool array [N,D,H,W,C]}, 'pool': [float32 arrays]} -- the `pins`
+        an oracle evaluation takes to differentiate the same piecewise-linear branch."""
+        import ctypes as C
+        out = {"relu": {}, "pool": [], "relu_sites": 0}
+        n = lib().p3d_debug_decision_count(self._h)
+        for i in range(n):
+            kind, n1, n2 = C.c_char_p(), C.c_char_p(), C.c_char_p()
+            shape = (C.c_int64 * 5)()
+            check(lib().p3d_debug_decision_info(self._h, i, C.byref(kind), C.byref(n1), C.byref(n2), shape))
+            shp = tuple(int(v) for v in shape)
+            a = np.empty(shp, np.float32)
+            if kind.value == b"pool":
+                check(lib().p3d_debug_decision_get(self._h, i, fptr(a), None, a.size))
+                out["pool"].append(a)
+                continue
+            b = np.empty(shp, np.float32)
+            check(lib().p3d_debug_decision_get(self._h, i, fptr(a), fptr(b), a.size))
+            out["relu_sites"] += 1
+            out["relu"][n1.value.decode()] = a != 0
+            if n2.value:
+                out["relu"][n2.value.decode()] = b != 0
+        return out
+
     def set_pointwise_fp16(self, enable=True):
         """BASELINE configs[4]: 1x1x1 convs on the fp16 matrix cores (fp32 accumulate, fp32 storage); fp16-level parity."""
         check(lib().p3d_set_pointwise_fp16(self._h, int(bool(enable))))
