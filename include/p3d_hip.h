@@ -132,6 +132,13 @@ int p3d_set_adam(p3d_handle* h, float lr, float beta1, float beta2, float eps);
 int p3d_activation_info(p3d_handle* h, const char* name, int64_t shape[5]);
 int p3d_get_activation(p3d_handle* h, const char* name, float* host, int64_t count);
 
+/* ---- schedule of one train step (TEST HOOK, tests/test_gpu_schedule.py): runs p3d_train_step_device once and writes every stream
+ *      operation it issued, in host issue order, one per line: "L <stream> <kernel> [@op]" (launch), "M <stream> <what>" (async
+ *      fill), "R <stream> e<k>" (event record), "W <stream> e<k>" (stream waits for event), "C <stream> allreduce <lo> <hi>".
+ *      Streams: main, side (filter gradients), comm (all-reduce).  `needed` receives the size of the text; call with a buffer
+ *      at least that large (a first call with text = NULL runs the step, too).  Synchronises. */
+int p3d_debug_schedule(p3d_handle* h, float dropout_rate, uint64_t seed, char* text, int64_t cap, int64_t* needed);
+
 /* ---- decisions of the last forward (TEST HOOK, tests/test_gpu_pinned.py): the ReLU gates and max-pool choices the backward pass of
  *      this handle will use -- so that the oracle can differentiate the SAME piecewise-linear branch (a float32 forward takes
  *      a handful of near-zero decisions differently from a float64 one, and each moves a gradient tensor by per cent).

@@ -52,6 +52,7 @@ SIGNATURES = {
     "p3d_set_attention_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "p3d_debug_dirty_counters": (C.c_int64, []),
     "p3d_debug_force_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "p3d_debug_schedule": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64, C.c_char_p, C.c_int64, _i64p]),
     "p3d_debug_decision_count": (C.c_int, [C.c_void_p]),
     "p3d_debug_decision_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _i64p]),
     "p3d_debug_decision_get": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, C.c_int64]),

@@ -174,6 +174,17 @@ class P3DSession:
         check(lib().p3d_block_backward(self._h, int(block_id), fptr(a), a.size, fptr(d), d.size, fptr(din)))
         return din
 
+    def schedule(self, dropout=0.5, seed=0):
+        """One train step on the resident inputs, returned as the list of stream operations it issued (p3d_debug_schedule; tests)."""
+        import ctypes as C
+        cap = 1 << 22
+        buf = C.create_string_buffer(cap)
+        need = C.c_int64(0)
+        check(lib().p3d_debug_schedule(self._h, float(dropout), int(seed), buf, cap, C.byref(need)))
+        if need.value > cap:
+            raise P3dError("schedule text of %d bytes does not fit" % need.value)
+        return buf.value.decode().splitlines()
+
     def decisions(self):
         """The ReLU gates and max-pool inputs of the last forward pass, as the backward pass of this session uses them
         (p3d_debug_decision_*; tests): {'relu': {BatchNorm scope: bool array [N,D,H,W,C]}, 'pool': [float32 arrays]} -- the `pins`
