@@ -238,6 +238,7 @@ def main():
     t_one = time.perf_counter() - t1
     sess.synchronize()
     plane.barrier()
+    t_one_max = plane.max_over_ranks(t_one)        # the slowest rank's host: what N ranks on one host's cores cost each other
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
@@ -277,6 +278,7 @@ def main():
             "launches_per_step": len(recs),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
             "host_enqueue_ms_one_step_empty_queue": round(1e3 * t_one, 3),
+            "host_enqueue_ms_one_step_empty_queue_max_over_ranks": round(1e3 * t_one_max, 3),
             "roofline": roofline_of(rows),
             "kernels": [dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["ms"], 3), avg_us=round(r["avg_us"], 2),
                              tflops=round(r["tflops"], 2), gbs=round(r["gbs"], 1)) for r in rows[:12]],
