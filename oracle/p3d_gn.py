@@ -21,7 +21,9 @@ def GroupNorm(g, x, G=32, esp=1e-5):
     C = x.data.shape[-1]
     gamma = g.variable(scope + '/gamma', (C,), g.ones)
     beta = g.variable(scope + '/beta', (C,), g.zeros)
-    return nn.group_norm(g.tape, x, gamma, beta, G, esp)
+    out = nn.group_norm(g.tape, x, gamma, beta, G, esp)
+    out.tag = scope              # relu() finds a pinned decision mask under this name (nn.Tape.pins)
+    return out
 
 
 def GNReLU(g, x):
@@ -262,10 +264,11 @@ def forward(params, x, dropout=0.0, training=False, cfg=None, dtype=np.float32, 
     return pred.data, g
 
 
-def loss_and_grads(params, x, y, dropout=0.0, training=True, cfg=None, dtype=np.float32, head='p3d', keep_mask=None):
+def loss_and_grads(params, x, y, dropout=0.0, training=True, cfg=None, dtype=np.float32, head='p3d', keep_mask=None, pins=None):
     """gn/train_p3d_gn_dataset.py:186: the same Smooth-L1 sum on the raw prediction."""
     from collections import OrderedDict
     g = Graph(params, dtype=dtype, create=False)
+    g.tape.pins = pins
     pred = HEADS[head](g, nn.Var(x.astype(dtype)), dropout, x.shape[0], training, cfg, keep_mask)
     loss = nn.smooth_l1_loss(g.tape, nn.reshape(g.tape, pred, y.shape), y.astype(dtype), 1, 1, sigma=1.0)
     g.tape.backward(loss)

@@ -703,9 +703,9 @@ WPlan plan(const WgradArgs& a, long long other_tiles = 0) {
     // Round 3, per-launch sweeps (tools/op_times.py --wgrad-tile): launches with 256 or more 64x64 tiles take part whatever their
     // position count (deconv1 at 8 clips of 16x112x112, 392 positions: 89 -> 69 us).  128x128 tiles win ALONE wherever there are
     // 128 or more of them (the GN head's 1792 -> 1024 conv 23.2 -> 21.9 ms, the unet++ decoder convs 6-11 %) and change
-    // nothing in the step (same-box A/B over five workloads, tools/ab_wgrad_big.sh: within 0.2 % either way): 64x128 stays.
+    // nothing in the step (same-box A/B over five workloads, tools/archive/ab_wgrad_big.sh: within 0.2 % either way): 64x128 stays.
     const bool busy = other_tiles == 0 && (M >= 2048 || tiles_of(a, 64, 64) >= 256) && a.Nc >= 128 && !wtune().no_rect && !forced;
-    static const bool big_tiles = [] { const char* e = p3d_tune_env("P3D_TUNE_WGRAD_BIG"); return e && atoi(e); }();      // A/B (tools/ab_wgrad_big.sh)
+    static const bool big_tiles = [] { const char* e = p3d_tune_env("P3D_TUNE_WGRAD_BIG"); return e && atoi(e); }();      // A/B (tools/archive/ab_wgrad_big.sh)
     if (busy && big_tiles && a.K >= 128 && tiles_of(a, 128, 128) >= 128) return best_for(128, 128);
     if (busy) return best_for(64, 128);
     WPlan best = best_for(64, 64);

@@ -356,6 +356,7 @@ struct Op {
     std::string dec_kind;                   // "" (none), "bn", "pool"
     std::string dec_name1, dec_name2;       // bn: TF scopes of the one or two BatchNorms
     const struct Act* dec_act = nullptr;    // bn: shape of the gated tensor; pool: the pool's input
+    int64_t dec_scratch = 0;                // floats of scratch the gates closure needs (0: 4 x channels)
     std::function<void(hipStream_t, const float* ones, float* o1, float* o2, float* scratch)> gates;
 };
 

@@ -88,7 +88,7 @@ def test_fused_train_steps_match_unfused_and_oracle():
     want = [p3d.train_step(p64, state, x.astype(np.float64), y.astype(np.float64), lr=1e-3, cfg=cfg, dtype=np.float64)[0] for _ in range(3)]
     for it in range(3):
         # Adam's first steps are lr * sign(g): weights whose gradient is noise-level take a different +-lr step than the
-        # oracle's, which the third loss shows at the 2e-4 level for BOTH launch lists (tests/probes/fused_probe.py)
+        # oracle's, which the third loss shows at the 2e-4 level for BOTH launch lists (tests/archive/probes/fused_probe.py)
         assert abs(runs[2][0][it] - want[it]) < 5e-4 * abs(want[it]), (it, runs[2][0][it], want[it])
         assert abs(runs[2][0][it] - runs[0][0][it]) < 5e-4 * abs(want[it])      # (the same +-lr steps: the two launch lists round differently)
     for n, v in runs[2][1].items():

@@ -566,7 +566,7 @@ def test_pointwise_fp16_mode():
     # Gradients: the head's (between the last pointwise conv and the loss) are fp16-accurate.  Deeper ones are not
     # comparable element by element at random initialisation: the 1e-3 forward perturbation flips ~1e-3 of all ReLU
     # decisions, and the gradient of this net decorrelates under such flips layer by layer (30 % rel-L2 at the stem,
-    # see tools/dd_probe.py for how short the linear range is) -- there the direction must survive: cosine >= 0.8.
+    # see tools/archive/dd_probe.py for how short the linear range is) -- there the direction must survive: cosine >= 0.8.
     for n, w in g64.items():
         got = s.get_grad(n).astype(np.float64)
         assert np.isfinite(got).all(), n
@@ -574,7 +574,7 @@ def test_pointwise_fp16_mode():
             assert rel_l2(got, w, 1e-2 * np.linalg.norm(w)) <= 5e-2, n
         elif np.linalg.norm(w) > 1e-6 * max(np.abs(l64), 1.0) and not n.endswith('bias'):
             cos = float((got * w).sum() / (np.linalg.norm(got) * np.linalg.norm(w)))
-            # measured (tests/probes/f16_cos_probe.py): the smallest cosines belong to block 0's 16-element BatchNorm
+            # measured (tests/archive/probes/f16_cos_probe.py): the smallest cosines belong to block 0's 16-element BatchNorm
             # vectors, 0.78 with BatchNorm fusion and 0.82 without; everything else is >= 0.88
             assert cos >= 0.7, (n, cos)
     s.set_pointwise_fp16(False)

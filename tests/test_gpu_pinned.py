@@ -131,3 +131,43 @@ def test_reference_architecture_on_the_hip_pass_own_decisions():
     assert float(np.median(list(live.values()))) <= 3e-3
     assert max(errs[n] for n in zero) <= 2e-1, sorted(((errs[n], n) for n in zero), reverse=True)[:3]
     s.close()
+
+
+# ---- GroupNorm + CBAM graphs (BASELINE configs[3]) --------------------------------------------------------------------------
+GN_CASES = [
+    ("gn_p3d", "p3d", p3d.NetConfig(base=16, blocks=(1, 1, 2)), (1, 16, 32, 32)),            # golden/gn_p3d_b16_112 (gate 1.1e-2)
+    ("gn_p3d_decoder", "decoder", p3d.NetConfig(base=16, blocks=(1, 1, 2)), (1, 16, 32, 32)),  # golden/gn_decoder_b16_112 (gate 1.3e-2)
+    ("gn_p3d_decoder", "decoder", p3d.NetConfig(base=16, blocks=(1, 1, 2)), (2, 16, 32, 32)),  # gn_decoder/base16_2x16x32x32 (gate 1.7e-2)
+]
+
+
+@pytest.mark.parametrize("structure,head,cfg,shape", GN_CASES)
+def test_gn_gradients_on_the_hip_pass_own_relu_and_pool_decisions(structure, head, cfg, shape):
+    """The GroupNorm + CBAM graphs with the ReLU gates of every GroupNorm pass and the max-pool choices pinned to the HIP pass's
+    (CBAM's own decisions -- the arg-max of its two max-pools and the ReLU of its 1/8-width MLP -- stay the oracle's: a flip there
+    would show here as an excess, and the printed line says whether one does)."""
+    from oracle import p3d_gn
+    from test_gpu_net import make_session
+    p64 = p3d_gn.init_params(1, cfg, dtype=np.float64, head=head)
+    rng = np.random.default_rng(7)
+    for k, v in p64.items():
+        if k.endswith('gamma'):
+            v[:] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith(('beta', '/bias')):
+            v[:] = rng.uniform(-0.3, 0.3, v.shape)
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    x = p3d.synthetic_clip(0, shape + (3,))
+    y = p3d.synthetic_target(3, shape)
+    s = make_session(cfg, shape, p32, structure)
+    loss, pred = s.backward(x, y, 0.0)
+    pins = s.decisions()
+    assert pins["relu_sites"] > 10 and len(pins["pool"]) >= 3
+    pins["relu"] = {k.split('/')[-1]: v for k, v in pins["relu"].items()}      # (the decoder head's variables live in scope 'P3D/')
+    l64, pr64, g64, g = p3d_gn.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True, cfg, np.float64, head=head, pins=pins)
+    log = g.tape.pin_log
+    assert log["relu"] >= pins["relu_sites"], (log, pins["relu_sites"])
+    assert abs(loss - l64) <= 1e-5 * abs(l64)
+    scale = np.median([np.linalg.norm(v) for v in g64.values()])
+    errs = {n: np.linalg.norm(s.get_grad(n).astype(np.float64) - w) / max(np.linalg.norm(w), 1e-2 * scale) for n, w in g64.items()}
+    _check("%s base%d %s" % (structure, cfg.base, "x".join(map(str, shape))), errs, log)
+    s.close()
