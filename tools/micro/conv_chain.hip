@@ -70,6 +70,8 @@ int main(int argc, char** argv) {
         {"L2conv1 f", B, 4, 14, 14, 512, 128, 1, 1, 1, 0}, {"L2convS f", B, 4, 14, 14, 128, 128, 1, 3, 3, 0},
         {"L2convT f", B, 4, 14, 14, 128, 128, 3, 1, 1, 0}, {"L2conv3 f", B, 4, 14, 14, 128, 512, 1, 1, 1, 0},
         {"L1convS f", B, 8, 28, 28, 64, 64, 1, 3, 3, 0},   {"L1conv3 f", B, 8, 28, 28, 64, 256, 1, 1, 1, 0},
+        {"L1conv1 f", B, 8, 28, 28, 256, 64, 1, 1, 1, 0},  {"L1conv1a f", B, 8, 28, 28, 64, 64, 1, 1, 1, 0},
+        {"L1conv1 d", B, 8, 28, 28, 64, 256, 1, 1, 1, 1},  {"L1conv3 d", B, 8, 28, 28, 256, 64, 1, 1, 1, 1},
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float* flush; const size_t flush_bytes = 512u << 20; CK(hipMalloc((void**)&flush, flush_bytes));
