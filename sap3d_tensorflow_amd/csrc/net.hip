@@ -74,6 +74,10 @@ struct Param {
     float* g = nullptr;     // device gradient (trainables)
 };
 
+// The stem: conv -> BatchNorm -> ReLU, and the conv has no input gradient.  The normalisation's backward then ends after its
+// reduce / finalize launches and hands its arguments to the conv's filter gradient, which applies it on its operand path.
+struct StemBnLink { bool enabled = false, pending = false; BnBwdArgs args; };
+
 struct Act {
     std::string name;
     int N = 0, D = 0, H = 0, W = 0, C = 0, ld = 0;
@@ -85,6 +89,8 @@ struct Act {
     bool whole_consumed = false;    // a consumer of the whole buffer (all views) is registered
     // BatchNorm fusion: a normalised tensor that the fused forward never stores; reading it (p3d_get_activation) runs this
     std::function<void(hipStream_t)> materialize;
+    // the stem conv's output: its BatchNorm's backward may leave the apply pass to the conv's filter gradient (stem_wgrad.hip)
+    std::shared_ptr<struct StemBnLink> stem_link;
     int64_t rows() const { return (int64_t)N * D * H * W; }
 };
 
@@ -483,8 +489,29 @@ std::vector<IgemmArgs> igemm_conv_input_side(const ConvGeo& g, int N, const floa
 // Filter gradient of the [1,kh,kw,3,Cout] stem conv on its packed form (conv(): "stem"): x4 is the 4-channel, W-padded copy
 // of the clip ([rows][Wp][4]), dw4 the packed gradient [kh][kw*4][Cout] (zeroed here); dw += its three real channels.
 void stem_filter_gradient(const Ctx& c, const ConvGeo& g, int N, int Wp, const float* x4, const float* dy, int ldy, int Cout, float* dw4,
-                          float* dw, float* dbias, bool greedy) {
+                          float* dw, float* dbias, bool greedy, float* onepass_part = nullptr, const BnBwdArgs* through_bn = nullptr) {
     const int KH = g.k[1], K4 = g.k[2] * 4;
+    if (onepass_part && !dbias && p3d_stem_wgrad_ok(g.k[0], g.k[1], g.k[2], 3, Cout, g.s[0], g.s[1], g.s[2], g.O[2])) {
+        // one pass over the output gradient (stem_wgrad.hip); through_bn: that gradient is the BatchNorm + ReLU OUTPUT's and
+        // the normalisation's backward apply pass runs on this kernel's operand path
+        StemWgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x4 = x4; a.Wp = Wp; a.Hi = g.I[1]; a.nimg = N * g.I[0]; a.Ho = g.O[1]; a.Wo = g.O[2]; a.pad_h = g.pad[1];
+        a.dy = dy; a.lddy = ldy; a.part = onepass_part; a.dw = dw;
+        if (through_bn) {
+            const BnBwdArgs& b = *through_bn;
+            a.fused = 1; a.dy = b.dz; a.lddy = b.lddz; a.y = b.y1; a.ldy = b.ld1;
+            a.scale = b.scale1; a.shift = b.shift1; a.mean = b.mean1; a.invstd = b.invstd1; a.gamma = b.gamma1; a.coef = b.coef1; a.batch = b.batch1;
+        }
+        const double rows = (double)a.nimg * a.Ho * a.Wo;
+        int nblocks = 1;
+        launch(c, through_bn ? "stem_wgrad_kernel<bn>" : "stem_wgrad_kernel", 2.0 * rows * KH * g.k[2] * 3 * Cout,
+               4.0 * rows * Cout * (through_bn ? 2 : 1), [&]() { return p3d_stem_wgrad(a, &nblocks, c.s); });
+        launch(c, "stem_wgrad_fold_kernel", 0, 4.0 * nblocks * KH * g.k[2] * 3 * Cout,
+               [&]() { return p3d_stem_wgrad_fold(onepass_part, nblocks, dw, c.s); });
+        return;
+    }
+    if (through_bn) throw P3dError("the stem's fused normalisation backward needs the one-pass filter gradient");
     if (!c.dry) HIPCHECK(hipMemsetAsync(dw4, 0, (size_t)KH * K4 * Cout * sizeof(float), c.s));
     WgradArgs wa;
     memset(&wa, 0, sizeof(wa));

@@ -515,6 +515,24 @@ hipError_t p3d_colsum(const float* dy, int ld, long M, int C, float* out, hipStr
 hipError_t p3d_stem_pad(const float* x, float* x4, long long rows, int W, int Wp, int pad, hipStream_t s);
 hipError_t p3d_stem_pack_w(const float* w, float* w4, int taps_hw, int Co, hipStream_t s);          // [kh*kw][3][Co] -> [kh*kw][4][Co]
 hipError_t p3d_stem_unpack_dw(const float* dw4, float* dw, int taps_hw, int Co, hipStream_t s);     // dw += the 3 real channels of dw4
+// stem filter gradient in one pass over the output gradient (stem_wgrad.hip): [1,7,7,3,64], stride [1,2,2], even output width
+struct StemWgradArgs {
+    const float* x4; int Wp; int Hi;           // the padded 4-channel copy of the clip [nimg*Hi][Wp][4] (p3d_stem_pad)
+    int nimg, Ho, Wo, pad_h;                   // nimg = N*D frames; SAME padding above the image
+    const float* dy; int lddy;                 // output gradient [nimg*Ho*Wo][64]; fused: the gradient of the BatchNorm + ReLU OUTPUT
+    int fused;                                 // 1: dy is differentiated through bn -> relu on the fly (bn_bwd_apply, mode 0)
+    const float* y; int ldy;                   // fused: the conv's output (the BatchNorm's input)
+    const float* scale; const float* shift; const float* mean; const float* invstd; const float* gamma;
+    const float* coef; int batch;              // fused: (sum g / M, sum g*xhat / M) per channel (bn_bwd_finalize); batch = 0: moving statistics
+    float* part;                               // scratch, p3d_stem_wgrad_part_floats() floats
+    float* dw;                                 // [7][7][3][64], added to
+    int chunks, chunks_per_img, chunks_per_block, pairs_per_wave, slots_per_wave, lds_row;      // set by the launcher
+    int reserved_[4];
+};
+bool p3d_stem_wgrad_ok(int kd, int kh, int kw, int Cin, int Cout, int sd, int sh, int sw, int Wo);
+long p3d_stem_wgrad_part_floats();
+hipError_t p3d_stem_wgrad(const StemWgradArgs& a, int* nblocks, hipStream_t s);                   // the blocks' partials -> a.part
+hipError_t p3d_stem_wgrad_fold(const float* part, int nblocks, float* dw, hipStream_t s);        // dw += the partials, in block order
 
 #ifdef __cplusplus
 }

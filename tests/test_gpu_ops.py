@@ -68,6 +68,36 @@ def test_conv3d_forward_and_grads(xs, k, co, s):
         close(got_dx, want_dx)
 
 
+STEM_CASES = [
+    (2, 4, 32, 32),        # 16 x 16 outputs: 8 pairs per output row
+    (1, 2, 30, 28),        # 15 x 14: rows above AND below the image in the last / first patches, runs that end mid-row
+    (1, 3, 37, 44),        # odd height: SAME padding 3 + 3
+    (3, 5, 18, 12),        # fewer pairs than one block's waves want: empty waves
+    (2, 16, 112, 112),     # the reference clip size, two clips: 256 blocks of 7 chunks, 14 pairs per wave and chunk (the unrolled variant)
+    (1, 3, 224, 224),      # 224-pixel clips: 28 pairs per wave and chunk, six staging loads per thread
+    (1, 2, 64, 200),       # wide rows on the generic variant
+]
+
+
+@pytest.mark.parametrize("shape", STEM_CASES)
+def test_stem_filter_gradient_in_one_pass(shape):
+    """firstconv1's filter gradient ([1,7,7,3,64], stride [1,2,2], even output width) on stem_wgrad.hip: all seven kernel rows in
+    one pass over the output gradient, operands straight into the MFMA layout (csrc/stem_wgrad.hip); p3d.py:172."""
+    from sap3d_tensorflow_amd import ops
+    rng = np.random.default_rng(sum(shape))
+    xs = shape + (3,)
+    x = rnd(rng, xs)
+    ws = (1, 7, 7, 3, 64)
+    s = (1, 2, 2)
+    oshape = (xs[0], xs[1], (xs[2] + 1) // 2, (xs[3] + 1) // 2, 64)
+    dy = rnd(rng, oshape)
+    want = nn.conv3d_backward_filter(x.astype(np.float64), dy.astype(np.float64), ws, s)
+    got = ops.conv3d_backprop_filter(x, ws, dy, s, with_bias=False)
+    close(got, want)
+    again = ops.conv3d_backprop_filter(x, ws, dy, s, with_bias=False)
+    assert np.array_equal(got, again)          # fixed summation order
+
+
 DECONV_CASES = [
     ((2, 1, 7, 7, 64), (1, 3, 3), 32, (2, 2, 2)),     # deconv1: k1 on the temporal axis
     ((1, 2, 6, 6, 64), (2, 3, 3), 16, (2, 2, 2)),     # deconv2: k2
