@@ -255,7 +255,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
         const float4 m1 = ld4(a.mean1 + c), i1 = ld4(a.invstd1 + c);
         float4 m2 = f4(0.f), i2 = f4(0.f);
         if (TWO) { m2 = ld4(a.mean2 + c); i2 = ld4(a.invstd2 + c); }
-        for (long long row = (long long)blockIdx.x * rpi + sub; row < a.M; row += (long long)gridDim.x * rpi) {
+        // two rows per trip, a grid stride apart, on two accumulator sets: twice the loads in flight per thread (the large tensors --
+        // stem / deconv3: 401 408 rows on 512 blocks -- ran at 2.5 TB/s on one row per trip), a fixed order all the same
+        const long long stride = (long long)gridDim.x * rpi;
+        float4 t1 = f4(0.f), tx1 = f4(0.f), t2 = f4(0.f), tx2 = f4(0.f);
+        long long row = (long long)blockIdx.x * rpi + sub;
+        for (; row + stride < a.M; row += 2 * stride) {
+            float4 g1, g2, y1, y2, h1, h2, z1, z2;
+            bn_bwd_gates<MODE>(a, row, c, g1, g2, y1, y2);
+            bn_bwd_gates<MODE>(a, row + stride, c, h1, h2, z1, z2);
+            s1 = add4(s1, g1);
+            sx1 = fma4(g1, mul4(sub4(y1, m1), i1), sx1);
+            t1 = add4(t1, h1);
+            tx1 = fma4(h1, mul4(sub4(z1, m1), i1), tx1);
+            if (TWO) {
+                s2 = add4(s2, g2);
+                sx2 = fma4(g2, mul4(sub4(y2, m2), i2), sx2);
+                t2 = add4(t2, h2);
+                tx2 = fma4(h2, mul4(sub4(z2, m2), i2), tx2);
+            }
+        }
+        if (row < a.M) {
             float4 g1, g2, y1, y2;
             bn_bwd_gates<MODE>(a, row, c, g1, g2, y1, y2);
             s1 = add4(s1, g1);
@@ -265,6 +285,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
                 sx2 = fma4(g2, mul4(sub4(y2, m2), i2), sx2);
             }
         }
+        s1 = add4(s1, t1); sx1 = add4(sx1, tx1);
+        if (TWO) { s2 = add4(s2, t2); sx2 = add4(sx2, tx2); }
     }
     float* r = red[tid];
     r[0] = s1.x; r[1] = s1.y; r[2] = s1.z; r[3] = s1.w; r[4] = sx1.x; r[5] = sx1.y; r[6] = sx1.z; r[7] = sx1.w;
@@ -708,7 +730,7 @@ int p3d_bn_bwd_parts(long M, int C) {
     const int rpi = 256 / (C >> 2);
     long long blocks = (M + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
     if (blocks < 1) blocks = 1;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 512) blocks = 512;       // (1024: no faster on the 401 408-row tensors, 2-6 us slower on stage 1's, finalize +0.6 us)
     return (int)blocks;
 }
 
