@@ -776,6 +776,17 @@ hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slot
     return hipGetLastError();
 }
 
+// A group of 3x3x3 / 1x3x3 convs over many positions with 128-wide outputs (the unet++ head's nodes) takes the 64x128 tile like such
+// a launch alone: p3d_unetplusplus_nonsa 56.3 -> 54.3 ms / step (tools/ab/wgrad_group_rect_ab.sh, same box; the other six
+// workloads within 0.2 %).  Groups that hold a bottleneck's 1x1x1 convs stay on 64x64: with those included the 32x224x224 step
+// lost 0.8 %.  P3D_TUNE_WGRAD_GROUP_RECT (tuning build): the position count from which, 0 = never.
+bool group_takes_rect(const std::vector<const WgradArgs*>& live) {
+    static const long long rect_rows = [] { const char* e = p3d_tune_env("P3D_TUNE_WGRAD_GROUP_RECT"); return e ? atoll(e) : 2048ll; }();
+    bool all = live.size() > 1 && rect_rows > 0 && !wtune().no_rect && g_force_tm == 0;
+    for (auto* a : live) all = all && (long long)a->N * a->Gd * a->Gh * a->Gw >= rect_rows && a->Nc % 128 == 0 && !a->pair && a->ntaps >= 9;
+    return all;
+}
+
 }  // namespace
 
 const char* p3d_wgrad2_variant(const WgradArgs& a) {
@@ -783,12 +794,20 @@ const char* p3d_wgrad2_variant(const WgradArgs& a) {
     return w.tm == 128 ? (w.tn == 128 ? "wgrad2_kernel<128,128>" : "wgrad2_kernel<128,64>")
                        : (w.tn == 128 ? "wgrad2_kernel<64,128>" : "wgrad2_kernel<64,64>");
 }
+const char* p3d_wgrad2_group_variant(const WgradArgs* probs, int n, bool fused) {
+    if (n == 1) return p3d_wgrad2_variant(probs[0]);
+    std::vector<const WgradArgs*> live;
+    for (int i = 0; i < n; ++i)
+        if ((long long)probs[i].N * probs[i].Gd * probs[i].Gh * probs[i].Gw > 0 && probs[i].ntaps > 0) live.push_back(&probs[i]);
+    if (group_takes_rect(live)) return fused ? "wgrad2_kernel<64,128,fused>(grouped)" : "wgrad2_kernel<64,128>(grouped)";
+    return fused ? "wgrad2_kernel<64,64,fused>(grouped)" : "wgrad2_kernel<64,64>(grouped)";
+}
 void p3d_wgrad2_force_tile(int tm, int tn) {
     const bool ok = (tm == 64 || tm == 128) && (tn == 64 || tn == 128);
     g_force_tm = ok ? tm : 0; g_force_tn = ok ? tn : 0;
 }
 
-// One launch for up to P3D_WGRAD_GROUP problems.  A single problem may take the 128x128 tile; groups use 64x64.
+// One launch for up to P3D_WGRAD_GROUP problems.  A single problem may take the 128x128 tile; groups use 64x64 (64x128: below).
 hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s) {
     std::vector<const WgradArgs*> live;
     for (int i = 0; i < n; ++i) {
@@ -806,7 +825,8 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
     g.zeros = live[0]->zeros;
     bool fused = false;
     for (auto* a : live) if (a->xt || a->dyt) fused = true;
-    const WPlan solo = live.size() == 1 ? plan(*live[0]) : WPlan{64, 64, 0, 1, 0.0};
+    WPlan solo = live.size() == 1 ? plan(*live[0]) : WPlan{64, 64, 0, 1, 0.0};
+    if (live.size() > 1 && group_takes_rect(live)) solo.tn = 128;
     const int tm = solo.tm, tn = solo.tn;
     long long tiles64_all = 0;
     for (auto* a : live) tiles64_all += tiles_of(*a, 64, 64);

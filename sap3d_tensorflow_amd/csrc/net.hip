@@ -829,7 +829,7 @@ struct p3d_handle {
         for (auto& q : wq) { probs.push_back(q.a); fl += q.flops; by += q.bytes; }
         bool any_fused = false;
         for (auto& pr : probs) any_fused |= pr.xt != 0 || pr.dyt != 0;
-        const char* name = probs.size() == 1 ? p3d_wgrad2_variant(probs[0]) : (any_fused ? "wgrad2_kernel<64,64,fused>(grouped)" : "wgrad2_kernel<64,64>(grouped)");
+        const char* name = p3d_wgrad2_group_variant(probs.data(), (int)probs.size(), any_fused);
         if (c.defer) {            // parked: it will run beside the encoder's chain of small launches -- low residency (conv_wgrad2.hip)
             for (auto& pr : probs) pr.polite = 1;
             parked_flops += fl;

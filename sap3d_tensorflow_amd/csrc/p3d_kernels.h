@@ -261,6 +261,7 @@ void p3d_igemm2_override(int tile, int splits);   // test / tools hook: force th
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s);   // up to P3D_WGRAD_GROUP problems, one launch
 const char* p3d_wgrad2_variant(const WgradArgs& a);
+const char* p3d_wgrad2_group_variant(const WgradArgs* probs, int n, bool fused);      // the label of a grouped launch (its tile)
 void p3d_wgrad2_force_tile(int tm, int tn);      // test hook: tile of single-problem launches (64 / 128 each); 0, 0 = the plan's choice
 
 // ---- BatchNorm (tf.layers.batch_normalization, rank-5, eps 1e-3) ------------------------------

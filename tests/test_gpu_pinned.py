@@ -63,6 +63,9 @@ CASES = [
     ("concat", p3d.NetConfig(base=16, blocks=(1, 2, 4)), (1, 16, 48, 32)),
     ("unet++nonsa", p3d.NetConfig(base=16, blocks=(1, 2, 4)), (1, 16, 48, 32)),    # unetpp_nonsa/base16_1x16x48x32 (gate 7.2e-3)
     ("unet++ds", p3d.NetConfig(base=16, blocks=(1, 1, 2)), (2, 16, 32, 32)),       # unetpp_ds/base16_2x16x32x32 (gate 4.3e-3)
+    # full width (base 64): the head's 3x3x3 convs have 128-wide outputs over >= 2048 positions, so their grouped filter-gradient
+    # launches take the 64x128 tile (conv_wgrad2.hip, p3d_launch_wgrad2_group) -- and the stem's runs on stem_wgrad.hip
+    ("unet++nonsa", p3d.NetConfig(base=64, blocks=(1, 1, 1)), (2, 16, 64, 64)),
 ]
 
 
@@ -79,6 +82,11 @@ def test_gradients_on_the_hip_pass_own_decisions(structure, cfg, shape):
     assert abs(loss - l64) <= 1e-5 * abs(l64)
     assert np.abs(pred - pr64).max() <= 3e-4
     _check("%s base%d %s" % (structure, cfg.base, "x".join(map(str, shape))), errs, log)
+    if cfg.base == 64:          # the full-width case is here for two kernels: make sure the launch list holds them
+        s.upload(x, y)
+        launches = [ln for ln in s.schedule(0.0, seed=0) if ln.startswith("L ")]
+        assert any("wgrad2_kernel<64,128>(grouped)" in ln for ln in launches), "no grouped filter-gradient launch on 64x128 tiles"
+        assert any("stem_wgrad" in ln for ln in launches), "the stem's filter gradient did not run on stem_wgrad.hip"
     s.close()
 
 
