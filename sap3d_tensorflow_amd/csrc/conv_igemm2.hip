@@ -49,8 +49,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BK = 32;
+#ifndef P3D_RING64
+#define P3D_RING64 3
+#endif
 template <int BM, int BN>
-struct Ring { static constexpr int stages = (BM >= 128) ? 2 : 3; };   // 64x64: deep ring, few steps per K-slice
+struct Ring { static constexpr int stages = (BM >= 128) ? 2 : P3D_RING64; };   // 64x64: deep ring, few steps per K-slice
 
 // operand transform traits
 template <int AT>
