@@ -20,14 +20,23 @@
 //  * FUSED: the BatchNorm + ReLU backward of the stem (bn_bwd_apply, mode 0) is evaluated on the B operand as it arrives
 //    (dy = k (g - c1 - xhat c2), g = dz where the normalised value is positive): the stem conv has no input gradient, so its
 //    output gradient is read by this kernel only and is never written -- one 309 MB elementwise pass less on the main stream;
-//  * the eight waves of a block fold their accumulators through LDS in wave order, the block writes ONE partial (37.6 KB) with
-//    plain stores, and stem_wgrad_fold_kernel sums the partials in a fixed order: bit-reproducible, no atomics.
+//  * the eight waves of a block put their accumulators into LDS side by side and every thread adds up, in wave order, the eight
+//    values of its output elements (sw_block_result); the block writes ONE partial (37.6 KB) with plain stores, and
+//    stem_wgrad_fold_kernel sums the partials in a fixed order: bit-reproducible, no atomics.
 //
-// Measured (8 clips of 16x112x112, `bench.py --kernels`): 122 us + 6 us fold = 62 TFLOP/s of the 7.6 GFLOP (0.39 of the fp32
-// matrix roof; SQ counters: matrix pipe busy 0.37 of the launch, waves parked on s_waitcnt 0.47) against 180 us + a 65 us
-// elementwise pass before.  Versions on the way: A operand gathered from global memory (5 loads per pair touching 4-6 cache
-// lines each) 152 us; LDS-staged with runtime cursors (60 scalar instructions per pair) 134 us; a one-thread-per-element fold of
-// the 256 partials cost 60 us by itself (32 dependent trips to memory).
+// Measured (8 clips of 16x112x112, `bench.py --kernels`): 82 us + 6 us fold = 92 TFLOP/s of the 7.6 GFLOP (0.59 of the fp32 matrix
+// roof) against 180 us + a 65 us elementwise pass before.  Versions on the way, and what each step was (tools/ab/stem_parts.sh
+// times the kernel with one ingredient compiled out, tools/micro/mfma_mix.hip the same instruction mix without memory):
+//   152 us  A operand gathered from global memory (5 loads per pair touching 4-6 cache lines each)
+//   134 us  LDS-staged, runtime cursors (60 scalar instructions per pair)
+//   122 us  tiled variant: compile-time slots, 7-stage ring; (a one-thread-per-element fold of the 256 partials: 60 us by itself)
+//   109 us  B operand through buffer loads (scalar offsets: six 64-bit per-lane pointers less, the staging registers no longer
+//           spill -- their reload drained the B pipeline at every chunk), one register set for A / B, LDS reads and arithmetic of
+//           the next slot placed between the MFMAs (sched_group_barrier)
+//    82 us  the block's result: eight waves side by side in LDS instead of seven rounds of dependent LDS read-add-write pairs
+//           (30 us: the kernel without its main loop took 40 us)
+// In the train step the kernel shares its 0.4 ms with Adam (346 us of HBM traffic on the main stream), so the step follows the
+// bytes, not this kernel: 15.44 -> 15.30 ms came with the first version and stayed there.
 #include <hip/hip_runtime.h>
 
 #include "p3d_kernels.h"
@@ -37,7 +46,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int SW_WAVES = 8, SW_THREADS = SW_WAVES * 64, SW_ROWS = 147, SW_TILES = 5, SW_CO = 64, SW_STAGES = 4, SW_AHEAD = 3;
 constexpr int SW_ELEMS = SW_ROWS * SW_CO;
 constexpr int SW_RC = 4, SW_SLOTS = 2 * SW_RC + 5;      // output rows per chunk; input rows a chunk touches
-constexpr int SW_RED_FLOATS = SW_TILES * 2 * 16 * 64;   // 40 KB: [tile][half][e][lane]
 
 struct SwStage { float2 z, y; };
 struct SwBn { float scale[2], shift[2], mean[2], invstd[2], k[2], c1[2], c2[2]; };
@@ -82,7 +90,11 @@ __device__ __forceinline__ void sw_b_operand(const SwStage& s, const SwBn& bn, f
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float d = z[h];
+#ifdef SW_EXP_NO_MATH
+        if (false) {
+#else
         if (FUSED) {       // bn_bwd_apply_kernel<0> (elementwise.hip), one element
+#endif
             const float v = fmaf(bn.scale[h], y[h], bn.shift[h]);
             const float g = v > 0.f ? z[h] : 0.f;
             const float xh = (y[h] - bn.mean[h]) * bn.invstd[h];       // (moving statistics: c1 = c2 = 0, d = k g)
@@ -92,28 +104,39 @@ __device__ __forceinline__ void sw_b_operand(const SwStage& s, const SwBn& bn, f
     }
 }
 
-// waves 7 .. 0 fold their accumulators through LDS, in that order; the block's partial goes out in [a][co] order
+// The block's result: the eight waves' accumulators summed in wave order.  In three phases (tiles 0-1, 2-3, 4) every wave puts its
+// accumulators of the phase's tiles into its own 16 KB of LDS -- all eight at once, 128 KB -- and every thread then adds up the eight
+// values of its output elements and writes them to the block's partial in [a][co] order.  (First version: one wave after the other
+// added its 160 registers into ONE 40 KB buffer, 7 rounds of 80 dependent LDS read-add-write pairs: 30 us of a 110 us kernel.)
+constexpr int SW_RES_PAIRS = 4;                                        // (tile, half) pairs per phase
+constexpr int SW_RES_FLOATS = SW_WAVES * SW_RES_PAIRS * 16 * 64;       // 128 KB
 __device__ __forceinline__ void sw_block_result(const f32x16 (&acc)[SW_TILES][2], float* red, float* part_all, int wave, int lane) {
-    for (int ww = SW_WAVES - 1; ww >= 0; --ww) {
-        if (wave == ww) {
+    float* part = part_all + (size_t)blockIdx.x * SW_ELEMS;
 #pragma unroll
-            for (int t = 0; t < SW_TILES; ++t)
+    for (int ph = 0; ph < 3; ++ph) {
+        const int t0 = 2 * ph, nt = ph < 2 ? 2 : 1;
+        __syncthreads();                 // the staged rows (or the previous phase) are read
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+            if (tl < nt)
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float* p = red + ((t * 2 + h) * 16 + e) * 64 + lane;
-                        *p = (ww == SW_WAVES - 1) ? acc[t][h][e] : *p + acc[t][h][e];
-                    }
-        }
+                    for (int e = 0; e < 16; ++e) red[(((wave * SW_RES_PAIRS) + tl * 2 + h) * 16 + e) * 64 + lane] = acc[t0 + tl][h][e];
         __syncthreads();
-    }
-    float* part = part_all + (size_t)blockIdx.x * SW_ELEMS;
-    for (int idx = threadIdx.x; idx < SW_ELEMS; idx += SW_THREADS) {
-        const int ai = idx >> 6, co = idx & 63;
-        const int t = ai >> 5, i = ai & 31, h = co & 1, j = co >> 1;      // lane j of half h holds channel 2j + h
-        const int hh = (i >> 2) & 1, e = (i & 3) + 4 * (i >> 3);          // accumulator row i = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-        part[idx] = red[((t * 2 + h) * 16 + e) * 64 + hh * 32 + j];
+        for (int o = threadIdx.x; o < nt * 32 * SW_CO; o += SW_THREADS) {
+            const int tl = o >> 11, i = (o >> 6) & 31, co = o & 63;
+            const int ai = 32 * (t0 + tl) + i;
+            if (ai < SW_ROWS) {
+                const int h = co & 1, j = co >> 1;                          // lane j of half h holds channel 2j + h
+                const int hh = (i >> 2) & 1, e = (i & 3) + 4 * (i >> 3);    // accumulator row i = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+                const float* src = red + ((tl * 2 + h) * 16 + e) * 64 + hh * 32 + j;
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < SW_WAVES; ++w) sum += src[w * SW_RES_PAIRS * 16 * 64];
+                part[ai * SW_CO + co] = sum;
+            }
+        }
     }
 }
 
@@ -248,10 +271,23 @@ __global__ __launch_bounds__(SW_THREADS) void stem_wgrad_kernel(StemWgradArgs a)
 // boundaries.  One slot = [B loads of slot j+6] [A reads + BatchNorm arithmetic of slot j+1] [10 MFMAs of slot j] in ONE
 // basic block per chunk, so the loads and the arithmetic issue in the shadow of the matrix pipe.
 constexpr int SW_RING = 7;
+// The B operand through buffer loads: the tensor's descriptor and the wave-uniform byte offset of the pair sit in scalar registers,
+// the lane's part of the address is ONE 32-bit register for the whole kernel -- no per-lane pointer arithmetic (the flat form kept
+// six 64-bit pointers in vector registers, and the staging registers spilled)
+typedef float sw_v2f __attribute__((ext_vector_type(2)));
+struct SwRsrc { __amdgpu_buffer_rsrc_t z, y; };
 template <bool FUSED>
-__device__ __forceinline__ void sw_load_at(SwStage& s, const float* pz, const float* py) {
-    s.z = *reinterpret_cast<const float2*>(pz);
-    if (FUSED) s.y = *reinterpret_cast<const float2*>(py);
+__device__ __forceinline__ void sw_load_at(SwStage& s, const SwRsrc& rs, int off_z, int off_y, int lane_z, int lane_y) {
+#ifdef SW_EXP_NO_B
+    s.z = make_float2(__builtin_bit_cast(float, off_z + lane_z), 1.f); s.y = s.z; (void)off_y; (void)lane_y;
+#else
+    const sw_v2f z = __builtin_bit_cast(sw_v2f, __builtin_amdgcn_raw_buffer_load_b64(rs.z, lane_z, off_z, 0));
+    s.z = make_float2(z.x, z.y);
+    if (FUSED) {
+        const sw_v2f y = __builtin_bit_cast(sw_v2f, __builtin_amdgcn_raw_buffer_load_b64(rs.y, lane_y, off_y, 0));
+        s.y = make_float2(y.x, y.y);
+    }
+#endif
 }
 
 template <bool FUSED, int NST, int PER>
@@ -324,67 +360,97 @@ __global__ __launch_bounds__(SW_THREADS) void stem_wgrad_tiled_kernel(StemWgradA
         }
     };
     // B operand of the wave's first pair of a chunk (positions are contiguous along a row and from row to row: pair j is 2 j further)
-    const long long lane_z = (long long)k * a.lddy + 2 * l31, lane_y = (long long)k * a.ldy + 2 * l31;
-    auto b_base = [&](int chunk, const float*& pz, const float*& py) {
-        const long long pos = (long long)chunk * SW_RC * a.Wo + (long long)r * a.Wo + 2 * pw0;      // chunks tile the images: Ho % 4 == 0
-        pz = a.dy + pos * a.lddy + lane_z;
-        py = FUSED ? a.y + pos * a.ldy + lane_y : nullptr;
+    // B operand of the wave's first pair of a chunk (positions are contiguous along a row and from row to row: pair j is 2 j further):
+    // byte offsets, wave-uniform; the launcher checked that the tensors are smaller than 2 GB
+    const int lane_z = (k * a.lddy + 2 * l31) * 4, lane_y = (k * a.ldy + 2 * l31) * 4;
+    const long long npos = (long long)a.nimg * a.Ho * a.Wo;
+    SwRsrc rs;
+    rs.z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)(npos * a.lddy * 4), 0x00020000);
+    rs.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FUSED ? a.y : a.dy), 0, (int)(npos * (FUSED ? a.ldy : a.lddy) * 4), 0x00020000);
+    auto b_base = [&](int chunk, int& oz, int& oy) {
+        const int pos = chunk * SW_RC * a.Wo + r * a.Wo + 2 * pw0;      // chunks tile the images: Ho % 4 == 0
+        oz = pos * a.lddy * 4;
+        oy = pos * a.ldy * 4;
     };
-    const long long step_z = 2LL * a.lddy, step_y = 2LL * a.ldy;
+    const int step_z = 8 * a.lddy, step_y = 8 * a.ldy;
 
     float4 stg[NST];
     stage_load(chunk0, stg);
     stage_store(chunk0, 0, stg);
     SwStage st[SW_RING];
-    const float *pz, *py;
+    int pz, py;
     b_base(chunk0, pz, py);
 #pragma unroll
-    for (int j = 0; j < SW_RING - 1; ++j) sw_load_at<FUSED>(st[j], pz + j * step_z, FUSED ? py + j * step_y : nullptr);
+    for (int j = 0; j < SW_RING - 1; ++j) sw_load_at<FUSED>(st[j], rs, pz + j * step_z, py + j * step_y, lane_z, lane_y);
     sw_barrier();
-    float av[2][SW_TILES], b[2][2];
+    float av[SW_TILES], b[2];
     {
         const float* __restrict__ rows = sw_lds;
 #pragma unroll
-        for (int t = 0; t < SW_TILES; ++t) av[0][t] = rows[aoff[t]];
-        sw_b_operand<FUSED>(st[0], bn, b[0]);
+        for (int t = 0; t < SW_TILES; ++t) av[t] = rows[aoff[t]];
+        sw_b_operand<FUSED>(st[0], bn, b);
     }
+#ifdef SW_EXP_NO_LOOP
+    for (int chunk = chunk0; chunk < chunk0 + (a.Wp > 100000); ++chunk) {
+#else
     for (int chunk = chunk0; chunk < chunk_end; ++chunk) {
+#endif
         const int buf = (chunk - chunk0) & 1;
         const bool more = chunk + 1 < chunk_end;
         const int next = more ? chunk + 1 : chunk;        // (the block's last chunk: the ring re-reads its own first pairs, unused)
+#ifndef SW_EXP_NO_STAGE
         stage_load(next, stg);
-        const float *pzn, *pyn;
+#endif
+        int pzn, pyn;
         b_base(next, pzn, pyn);
         const float* __restrict__ rows = sw_lds + buf * buf_words;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             constexpr int AH = SW_RING - 1;
             const int jl = j + AH;                        // the slot whose B operand is requested now
-            if (jl < PER) sw_load_at<FUSED>(st[jl % SW_RING], pz + jl * step_z, FUSED ? py + jl * step_y : nullptr);
-            else sw_load_at<FUSED>(st[jl % SW_RING], pzn + (jl - PER) * step_z, FUSED ? pyn + (jl - PER) * step_y : nullptr);
+            if (jl < PER) sw_load_at<FUSED>(st[jl % SW_RING], rs, pz + jl * step_z, py + jl * step_y, lane_z, lane_y);
+            else sw_load_at<FUSED>(st[jl % SW_RING], rs, pzn + (jl - PER) * step_z, pyn + (jl - PER) * step_y, lane_z, lane_y);
             __builtin_amdgcn_sched_barrier(0);            // the loads stay in their slot (the scheduler would bunch them up, and drain)
-            if (j + 1 < PER) {
+            // a tile's two MFMAs, then the A operand of the NEXT slot into the register they just read; the next slot's B operand
+            // (the BatchNorm arithmetic) spread between them
+            float nb[2] = {0.f, 0.f};
+            if (j + 1 < PER) sw_b_operand<FUSED>(st[(j + 1) % SW_RING], bn, nb);
 #pragma unroll
-                for (int t = 0; t < SW_TILES; ++t) av[(j + 1) & 1][t] = rows[aoff[t] + 16 * (j + 1)];
-                sw_b_operand<FUSED>(st[(j + 1) % SW_RING], bn, b[(j + 1) & 1]);
+            for (int t = 0; t < SW_TILES; ++t) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc[t][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b[h], acc[t][h], 0, 0, 0);
+#ifdef SW_EXP_NO_A
+                if (j + 1 < PER) av[t] = av[t] + 1.f;
+#else
+                if (j + 1 < PER) av[t] = rows[aoff[t] + 16 * (j + 1)];
+#endif
             }
+            b[0] = nb[0]; b[1] = nb[1];
 #pragma unroll
-            for (int t = 0; t < SW_TILES; ++t)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) acc[t][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][t], b[j & 1][h], acc[t][h], 0, 0, 0);
+            for (int q = 0; q < SW_TILES; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef SW_EXP_NO_STAGE
         if (more) stage_store(next, buf ^ 1, stg);
         sw_barrier();
-        if (more) {       // slot 0 of the next chunk (PER is even: register set 0 again)
+#endif
+        if (more) {       // slot 0 of the next chunk
             const float* __restrict__ nrows = sw_lds + (buf ^ 1) * buf_words;
 #pragma unroll
-            for (int t = 0; t < SW_TILES; ++t) av[0][t] = nrows[aoff[t]];
-            sw_b_operand<FUSED>(st[0], bn, b[0]);
+            for (int t = 0; t < SW_TILES; ++t) av[t] = nrows[aoff[t]];
+            sw_b_operand<FUSED>(st[0], bn, b);
         }
         pz = pzn; py = pyn;
     }
+#ifndef SW_EXP_NO_EPILOGUE
     sw_block_result(acc, sw_lds, a.part, wave, lane);
+#else
+    if (acc[0][0][0] == 123.f) a.part[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7] + acc[4][0][9];
+#endif
 }
 
 // dw [7][7][3][64] += the blocks' partials.  16 lanes per element, one batch of loads each (a single thread walking 256 partials
@@ -411,7 +477,7 @@ __global__ __launch_bounds__(64 * SW_FOLD_G) void stem_wgrad_fold_kernel(const f
 
 int sw_lds_row(int Wp) { return ((Wp * 4 + 31) / 64) * 64 + 32; }       // >= Wp*4 and 32 mod 64
 size_t sw_lds_bytes(int Wp) {
-    const size_t stage = (size_t)2 * SW_SLOTS * sw_lds_row(Wp) * sizeof(float), red = (size_t)SW_RED_FLOATS * sizeof(float);
+    const size_t stage = (size_t)2 * SW_SLOTS * sw_lds_row(Wp) * sizeof(float), red = (size_t)SW_RES_FLOATS * sizeof(float);
     return stage > red ? stage : red;
 }
 constexpr int SW_MAX_WP = 236;       // 6 staging loads per thread: clips up to 231 pixels wide
@@ -468,7 +534,9 @@ hipError_t p3d_stem_wgrad(const StemWgradArgs& a0, int* nblocks, hipStream_t s) 
     const int nst = (SW_SLOTS * a.Wp + SW_THREADS - 1) / SW_THREADS;
     hipError_t e;
     static const bool no_tiled = p3d_tune_env("P3D_STEM_TILED") && atoi(p3d_tune_env("P3D_STEM_TILED")) == 0;      // A/B runs
-    const bool tiles = !no_tiled && a.Ho % SW_RC == 0 && SW_RC * (a.Wo >> 1) == SW_WAVES * a.pairs_per_wave;
+    const long long npos = (long long)a.nimg * a.Ho * a.Wo;
+    const bool small = npos * a.lddy * 4 < (1ll << 31) && (!a.fused || npos * a.ldy * 4 < (1ll << 31));      // buffer descriptors: 2 GB
+    const bool tiles = !no_tiled && small && a.Ho % SW_RC == 0 && SW_RC * (a.Wo >> 1) == SW_WAVES * a.pairs_per_wave;
     const unsigned nb = (unsigned)blocks;
     if (tiles && a.pairs_per_wave == 14 && nst <= 3) e = a.fused ? sw_launch_tiled<true, 3, 14>(a, nb, lds, s) : sw_launch_tiled<false, 3, 14>(a, nb, lds, s);
     else if (tiles && a.pairs_per_wave == 28 && nst <= 6) e = a.fused ? sw_launch_tiled<true, 6, 28>(a, nb, lds, s) : sw_launch_tiled<false, 6, 28>(a, nb, lds, s);
