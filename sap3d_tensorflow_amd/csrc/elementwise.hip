@@ -635,11 +635,23 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
     }
     if (!p3d_last_block_wt(counters, gridDim.x, &last_flag)) return;
     acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live)
-        for (unsigned b = rs; b < gridDim.x; b += R) {
-            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)b * C + lane * 4);
+    if (live) {
+        // the partials come from other CUs' write-through stores: every load is a long-latency miss, so eight in flight (one at a
+        // time this fold was 40 of deconv3's 62 us: 64 dependent trips), added in the same order
+        const float* src = part + lane * 4;
+        unsigned b = rs;
+        for (; b + 7u * R < gridDim.x; b += 8u * R) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(b + u * R) * C);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; b < gridDim.x; b += R) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)b * C);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+    }
     __syncthreads();
     red[threadIdx.x] = acc;
     __syncthreads();
