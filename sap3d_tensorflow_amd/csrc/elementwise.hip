@@ -473,14 +473,25 @@ __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* pred, const
     __shared__ double wsum[4];
     __shared__ int last_flag;
     double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float p = pred[i];
-        const float d = p - target[i];
+    auto one = [&](float p, float t, float& g) {
+        const float d = p - t;
         const float ad = fabsf(d);
         acc += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
-        float g = ad < 1.f ? d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        g = ad < 1.f ? d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
         if (through_sigmoid) g *= p * (1.f - p);
-        dl[i] = g;
+    };
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long long)gridDim.x * blockDim.x;
+    if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(dl)) & 15) == 0) {
+        // 16 bytes per lane and tensor (the scalar form ran at 0.86 TB/s: 22 us for 19 MB on the main stream)
+        const long long n4 = n >> 2;
+        for (long long i = gtid; i < n4; i += gsz) {
+            const float4 p = ld4(pred + 4 * i), t = ld4(target + 4 * i);
+            float4 g;
+            one(p.x, t.x, g.x); one(p.y, t.y, g.y); one(p.z, t.z, g.z); one(p.w, t.w, g.w);
+            st4(dl + 4 * i, g);
+        }
+    } else {
+        for (long long i = gtid; i < n; i += gsz) one(pred[i], target[i], dl[i]);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
