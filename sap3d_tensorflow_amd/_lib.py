@@ -4,7 +4,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp3dhip.so")
+# P3D_LIB: another build of the same library (same-box A/Bs against an older round's, tools/ab/); every declared symbol must
+# still bind, so it cannot be anything else
+LIB_PATH = os.environ.get("P3D_LIB") or os.path.join(_HERE, "libp3dhip.so")
 
 P3D_COMM_ID_BYTES = 128
 

@@ -31,10 +31,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _flags_key():
+    """The compile flags are part of an object's identity: an A/B build with -DSOMETHING must never be reused by the next
+    plain build (objects used to be cached by source mtime alone)."""
+    import hashlib
+    return hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()[:16]
+
+
 def build(verbose=False, force=False):
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    keyfile = os.path.join(objdir, "flags.key")
+    key = _flags_key()
+    if not os.path.exists(keyfile) or open(keyfile).read().strip() != key:
+        force = True            # objects built with other flags (or before the key existed) are not ours
     jobs = []
     objs = []
     for src in SOURCES:
@@ -59,6 +70,8 @@ def build(verbose=False, force=False):
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
             ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+    with open(keyfile, "w") as f:      # written last: an interrupted build leaves the old key and is redone
+        f.write(key + "\n")
     return LIB
 
 

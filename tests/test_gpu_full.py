@@ -493,3 +493,51 @@ def test_configs4_workload_fp16_pointwise_batch8():
     b = s.train_step(x, y, dropout=0.5, seed=2)
     assert np.isfinite(a) and np.isfinite(b)
     s.close()
+
+
+def test_gn_head_at_full_width_against_the_oracle():
+    """The head of inference_p3d (gn/p3d_gn.py:234-257) at the REFERENCE widths, inside the train step's own schedule: base 64
+    with one bottleneck per stage keeps the float64 oracle affordable while deconv_pool3 (512 -> 512), deconv_pool4 (kernel 3,
+    stride 4, 1024 -> 1024), conv_concat (3x3x3, 1792 -> 1024 on 4x28x28: 311 of the net's 382 GFLOP per clip), deconv_revise
+    (1024 -> 256) and predict_revise (256 -> 1) run at full size on 2 clips.  Map and loss against float64; every HEAD gradient
+    (kernels, biases, GroupNorm gamma / beta) within the plain fp32-noise bound 5 x (float32 oracle's distance) + 2e-3, no
+    measured allowance; the three encoder bottlenecks (CBAM arg-max routing) go through the measured gate."""
+    from oracle import p3d_gn
+    from gates import check, noise_excess
+    from sap3d_tensorflow_amd import P3DSession
+    cfg = p3d.NetConfig(base=64, blocks=(1, 1, 1))
+    shape = (2, 16, 112, 112)
+    p64 = _gn_params64(cfg)
+    p32 = {k: v.astype(np.float32) for k, v in p64.items()}
+    x = p3d.synthetic_clip(0, shape + (3,))
+    y = p3d.synthetic_target(3, shape)
+    s = P3DSession('gn_p3d', batch=shape[0], frames=shape[1], height=shape[2], width=shape[3], base=cfg.base, blocks=cfg.blocks)
+    s.load(p32)
+    assert [n for n, _, _ in s.variables()] == list(p64)
+    l64, pr64, g64, graph = p3d_gn.loss_and_grads(p64, x.astype(np.float64), y.astype(np.float64), 0.0, True, cfg, np.float64)
+    loss, pred = s.backward(x, y, 0.0)
+    for name in ['conv_concat']:
+        want = graph.tape.taps[name].data
+        got = s.activation(name)
+        assert got.shape == want.shape, name
+        assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0), name
+    assert np.abs(pred - pr64).max() <= 1e-4 * max(np.abs(pr64).max(), 1.0)
+    assert abs(loss - l64) < 1e-5 * abs(l64)
+    _, _, g32, _ = p3d_gn.loss_and_grads(dict(p32), x, y, 0.0, True, cfg, np.float32)
+    floor = 1e-2 * np.median([np.linalg.norm(v) for v in g64.values()])
+    e_hip = {n: rel_l2(s.get_grad(n), w, floor) for n, w in g64.items()}
+    e_o32 = {n: rel_l2(g32[n], w, floor) for n, w in g64.items()}
+    s.close()
+    names = list(g64)
+    head0 = names.index('deconv_pool4/kernel')
+    head = [n for n in names[head0:]] + [n for n in names if n.startswith('deconv_pool3')]
+    # GroupNorm scopes are numbered in creation order: the ones created after deconv_pool4 belong to the head, and
+    # deconv_pool3's is the one right behind its bias
+    k3 = names.index('deconv_pool3/bias')
+    head += [n for n in names[k3 + 1:k3 + 3] if n.startswith('group_norm')]
+    assert any(n == 'conv_concat/kernel' for n in head) and any(n == 'predict_revise/kernel' for n in head) and len(head) >= 18
+    worst, who = noise_excess({n: e_hip[n] for n in head}, e_o32)
+    assert worst == 0.0, ("a head gradient lies above the fp32-noise bound", who, e_hip[who], e_o32[who])
+    rest = {n: e for n, e in e_hip.items() if n not in head}
+    excess, name = noise_excess(rest, e_o32)
+    check("gn_head_full/encoder", excess, detail=(name, rest.get(name), e_o32.get(name)))

@@ -332,3 +332,69 @@ def test_conv3d_transpose_at_deconv3_size():
     assert got.shape == want.shape
     close(got, want)
     assert np.array_equal(got, ops.conv3d_transpose(x, kern, s, bias=b))
+
+
+# ---- the head of inference_p3d (gn/p3d_gn.py:234-257) at FULL width: conv_concat is 311 of the net's 382 GFLOP per clip --------
+# The longest reduction of these launches is K = 27 x 1792 = 48384 terms (the bottleneck convs: <= 2304), so the tolerance is
+# stated per case: an fp32 sum of n terms of magnitude ~s sits ~eps*sqrt(n)*s from float64 whatever its order.
+GN_HEAD_CONVS = [
+    # (x shape, kernel, Cout, strides, tolerance)
+    ((1, 4, 28, 28, 1792), (3, 3, 3), 1024, (1, 1, 1), 2e-5),     # conv_concat on the concatenator of ONE clip
+    ((1, 2, 10, 10, 1792), (3, 3, 3), 1024, (1, 1, 1), 2e-5),     # ... on a lattice where most positions touch the SAME padding
+]
+
+
+@pytest.mark.parametrize("xs,k,co,s,tol", GN_HEAD_CONVS)
+def test_gn_head_conv_concat_at_full_width(xs, k, co, s, tol):
+    """conv_concat (gn/p3d_gn.py:253: 3x3x3, 1792 -> 1024 on 4x28x28 per clip): forward, input gradient, filter gradient and
+    bias gradient through the C ABI's op entry points against the float64 oracle."""
+    from sap3d_tensorflow_amd import ops
+    rng = np.random.default_rng(1792)
+    x = rnd(rng, xs)
+    w = rnd(rng, k + (xs[4], co)) * 0.02
+    b = rnd(rng, (co,))
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    want = nn.conv3d_forward(x64, w64, s) + b
+    got = ops.conv3d(x, w, s, bias=b)
+    close(got, want, tol)
+    assert np.array_equal(got, ops.conv3d(x, w, s, bias=b))
+    dy = rnd(rng, want.shape)
+    dy64 = dy.astype(np.float64)
+    close(ops.conv3d_backprop_input(xs, w, dy, s), nn.conv3d_backward_input(dy64, w64, s, xs), tol)
+    got_dw, got_db = ops.conv3d_backprop_filter(x, w.shape, dy, s, with_bias=True)
+    close(got_dw, nn.conv3d_backward_filter(x64, dy64, w.shape, s), tol)
+    close(got_db, dy64.reshape(-1, co).sum(0), tol)
+
+
+GN_HEAD_DECONVS = [
+    ((1, 1, 7, 7, 1024), (3, 3, 3), 1024, (4, 4, 4)),     # deconv_pool4 (gn/p3d_gn.py:245): kernel 3, stride 4, 1024 -> 1024
+    ((1, 2, 14, 14, 512), (3, 3, 3), 512, (2, 2, 2)),     # deconv_pool3 (:239): 512 -> 512
+    ((1, 4, 28, 28, 1024), (3, 3, 3), 256, (2, 2, 2)),    # deconv_revise (:255): 1024 -> 256 onto 8x56x56
+]
+
+
+@pytest.mark.parametrize("xs,k,co,s", GN_HEAD_DECONVS)
+def test_gn_head_transposed_convs_at_full_width(xs, k, co, s):
+    """The transposed convs of the inference_p3d head at the reference widths, forward (tf.layers.conv3d_transpose) and both
+    gradients: the input gradient of a transposed conv is the forward conv with the same kernel read [.., Cout, Cin], its filter
+    gradient the conv filter gradient with the roles of input and output gradient swapped (net_ops.inc, deconv())."""
+    from sap3d_tensorflow_amd import ops
+    rng = np.random.default_rng(co + xs[4])
+    x = rnd(rng, xs)
+    kern = rnd(rng, k + (co, xs[4])) * 0.03
+    b = rnd(rng, (co,))
+    t = nn.Tape()
+    X, K, Bv = nn.Var(x.astype(np.float64)), nn.Var(kern.astype(np.float64)), nn.Var(b.astype(np.float64))
+    Y = nn.conv3d_transpose(t, X, K, s, Bv)
+    got = ops.conv3d_transpose(x, kern, s, bias=b)
+    assert got.shape == Y.data.shape
+    close(got, Y.data)
+    dy = rnd(rng, Y.data.shape)
+    Y.grad = dy.astype(np.float64)
+    for fn in reversed(t.ops):
+        fn()
+    # y = conv_transpose(x, kern)  <=>  x' = conv(y', w = kern) is its adjoint: dx = conv3d(dy, kern, s), dkern = filter gradient of
+    # that conv with (input = dy, output gradient = x)
+    close(ops.conv3d(dy, kern, s), X.grad)
+    close(ops.conv3d_backprop_filter(dy, kern.shape, x, s), K.grad)
+    close(ops.bias_add_grad(dy), Bv.grad)
