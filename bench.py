@@ -214,8 +214,15 @@ def main():
         sess.set_attention_mode(args.attention)
     if args.bn_fusion != "default":
         sess.set_bn_fusion({"off": 0, "fwd": 1, "full": 2}[args.bn_fusion])
+    rccl_ranks = None
     if world > 1 and not rehearsal:
         sess.comm_init(plane.share_from_rank0(P3DSession.comm_unique_id))
+        # what RCCL itself says: every rank must sit in ONE communicator of `world` ranks, with its own rank number, on its own GPU
+        n, r, d = sess.comm_info()
+        if (n, r, d) != (world, rank, local_rank):
+            raise SystemExit("rank %d: RCCL communicator has %d ranks (this one: %d, device %d), expected %d / %d / %d" %
+                             (rank, n, r, d, world, rank, local_rank))
+        rccl_ranks = n
     x = synthetic.synthetic_clip(rank, (B, T, S, S, 3))
     y = synthetic.synthetic_target(3 + rank, (B, T, S, S))
     sess.upload(x, y)
@@ -276,6 +283,7 @@ def main():
             "final_loss": loss,
             "bn_fusion": args.bn_fusion, "attention": args.attention,
             "launches_per_step": len(recs),
+            **({"rccl_ranks": rccl_ranks} if world > 1 else {}),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
             "host_enqueue_ms_one_step_empty_queue": round(1e3 * t_one, 3),
             "host_enqueue_ms_one_step_empty_queue_max_over_ranks": round(1e3 * t_one_max, 3),

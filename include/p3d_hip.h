@@ -191,6 +191,10 @@ int p3d_profile_step(p3d_handle* h, float dropout_rate, uint64_t seed, p3d_op_ti
 #define P3D_COMM_ID_BYTES 128
 int p3d_comm_unique_id(void* id_out);
 int p3d_comm_init(p3d_handle* h, const void* id);
+/* What RCCL itself says about the handle's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): *n_ranks = 0 when the
+ * handle has none.  bench.py prints it as "rccl_ranks" at N > 1 and refuses a run where it differs from --gpus, so that a scaling
+ * line cannot come from ranks that never met. */
+int p3d_comm_info(p3d_handle* h, int* n_ranks, int* rank, int* device);
 /* Audit of the bucketed gradient hand-over (test hook; needs no communicator).  Runs forward + loss + backward with
  * buckets of `bucket_floats` and, at every point where a bucket [lo, hi) of the flat gradient buffer would be handed to
  * the all-reduce, waits for the work queued so far and copies the range out instead.  Returns the number of buckets

@@ -71,6 +71,7 @@ SIGNATURES = {
     "p3d_profile_step": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64, C.POINTER(P3dOpTime), C.c_int]),
     "p3d_comm_unique_id": (C.c_int, [C.c_void_p]),
     "p3d_comm_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "p3d_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "p3d_debug_bucket_audit": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64, C.c_int64, _i64p, _i64p, C.POINTER(C.c_int32), C.c_int,
                                          _i64p, _i64p]),
     "p3d_op_conv3d": (C.c_int, [C.c_int, _fp, _i64p, _fp, _i64p, _ip, _fp, _fp]),

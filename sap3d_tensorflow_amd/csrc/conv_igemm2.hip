@@ -893,7 +893,9 @@ long long p3d_scratch_dirty_counters() {
         const Scratch& sc = kv.second;
         if (!sc.cnt || !sc.counters) continue;
         std::vector<unsigned> h(sc.counters);
-        if (hipMemcpy(h.data(), sc.cnt, sc.counters * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (hipMemcpyAsync(h.data(), sc.cnt, sc.counters * sizeof(unsigned), hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+            hipStreamSynchronize(nullptr) != hipSuccess)
+            return -1;      // (the device is idle: synchronised above)
         for (unsigned v : h) dirty += v != 0;
     }
     return dirty;

@@ -196,6 +196,19 @@ inline hipError_t ev_wait(hipStream_t s, hipEvent_t e) {
     if (g_trace) g_trace->lines.push_back("W " + g_trace->sname(s) + " e" + std::to_string(g_trace->eid(e)));
     return hipStreamWaitEvent(s, e, 0);
 }
+// Every fill and copy of this library NAMES ITS STREAM (round 5).  A bare hipMemset / hipMemcpy runs on the null stream, which
+// is not ordered against the handle's non-blocking streams: twice in two rounds such a call raced a launch (arrival counters
+// zeroed under a running kernel; decision-hook scratch zeroed while its gate kernels ran).  fill_now / copy_now enqueue on the
+// given stream and wait for it, so they are ordered after everything queued there and complete on return;
+// tests/test_abi_cpu.py fails on any other spelling in csrc/.
+inline hipError_t fill_now(void* p, int v, size_t bytes, hipStream_t s) {
+    const hipError_t e = hipMemsetAsync(p, v, bytes, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+inline hipError_t copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
 inline hipError_t fill_async(void* p, int v, size_t bytes, hipStream_t s, const char* what) {
     if (g_trace) g_trace->lines.push_back("M " + g_trace->sname(s) + " " + what);
     return hipMemsetAsync(p, v, bytes, s);
@@ -592,7 +605,7 @@ void ensure_zero_page() {
     if (g_zero_page) return;
     float* p = nullptr;
     HIPCHECK(hipMalloc((void**)&p, 1024));
-    HIPCHECK(hipMemset(p, 0, 1024));
+    HIPCHECK(fill_now(p, 0, 1024, nullptr));      // process-wide, once, before any launch reads it
     g_zero_page = p;
 }
 }  // namespace

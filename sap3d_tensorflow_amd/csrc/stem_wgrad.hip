@@ -37,6 +37,9 @@
 //           (30 us: the kernel without its main loop took 40 us)
 // In the train step the kernel shares its 0.4 ms with Adam (346 us of HBM traffic on the main stream), so the step follows the
 // bytes, not this kernel: 15.44 -> 15.30 ms came with the first version and stayed there.
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "stem_wgrad.hip sizes its staging ring for gfx950's 160 KB of LDS per CU (up to 128 KB per block)"
+#endif
 #include <hip/hip_runtime.h>
 
 #include "p3d_kernels.h"
@@ -90,11 +93,7 @@ __device__ __forceinline__ void sw_b_operand(const SwStage& s, const SwBn& bn, f
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float d = z[h];
-#ifdef SW_EXP_NO_MATH
-        if (false) {
-#else
         if (FUSED) {       // bn_bwd_apply_kernel<0> (elementwise.hip), one element
-#endif
             const float v = fmaf(bn.scale[h], y[h], bn.shift[h]);
             const float g = v > 0.f ? z[h] : 0.f;
             const float xh = (y[h] - bn.mean[h]) * bn.invstd[h];       // (moving statistics: c1 = c2 = 0, d = k g)
@@ -278,16 +277,12 @@ typedef float sw_v2f __attribute__((ext_vector_type(2)));
 struct SwRsrc { __amdgpu_buffer_rsrc_t z, y; };
 template <bool FUSED>
 __device__ __forceinline__ void sw_load_at(SwStage& s, const SwRsrc& rs, int off_z, int off_y, int lane_z, int lane_y) {
-#ifdef SW_EXP_NO_B
-    s.z = make_float2(__builtin_bit_cast(float, off_z + lane_z), 1.f); s.y = s.z; (void)off_y; (void)lane_y;
-#else
     const sw_v2f z = __builtin_bit_cast(sw_v2f, __builtin_amdgcn_raw_buffer_load_b64(rs.z, lane_z, off_z, 0));
     s.z = make_float2(z.x, z.y);
     if (FUSED) {
         const sw_v2f y = __builtin_bit_cast(sw_v2f, __builtin_amdgcn_raw_buffer_load_b64(rs.y, lane_y, off_y, 0));
         s.y = make_float2(y.x, y.y);
     }
-#endif
 }
 
 template <bool FUSED, int NST, int PER>
@@ -390,17 +385,11 @@ __global__ __launch_bounds__(SW_THREADS) void stem_wgrad_tiled_kernel(StemWgradA
         for (int t = 0; t < SW_TILES; ++t) av[t] = rows[aoff[t]];
         sw_b_operand<FUSED>(st[0], bn, b);
     }
-#ifdef SW_EXP_NO_LOOP
-    for (int chunk = chunk0; chunk < chunk0 + (a.Wp > 100000); ++chunk) {
-#else
     for (int chunk = chunk0; chunk < chunk_end; ++chunk) {
-#endif
         const int buf = (chunk - chunk0) & 1;
         const bool more = chunk + 1 < chunk_end;
         const int next = more ? chunk + 1 : chunk;        // (the block's last chunk: the ring re-reads its own first pairs, unused)
-#ifndef SW_EXP_NO_STAGE
         stage_load(next, stg);
-#endif
         int pzn, pyn;
         b_base(next, pzn, pyn);
         const float* __restrict__ rows = sw_lds + buf * buf_words;
@@ -419,11 +408,7 @@ __global__ __launch_bounds__(SW_THREADS) void stem_wgrad_tiled_kernel(StemWgradA
             for (int t = 0; t < SW_TILES; ++t) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) acc[t][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b[h], acc[t][h], 0, 0, 0);
-#ifdef SW_EXP_NO_A
-                if (j + 1 < PER) av[t] = av[t] + 1.f;
-#else
                 if (j + 1 < PER) av[t] = rows[aoff[t] + 16 * (j + 1)];
-#endif
             }
             b[0] = nb[0]; b[1] = nb[1];
 #pragma unroll
@@ -434,10 +419,8 @@ __global__ __launch_bounds__(SW_THREADS) void stem_wgrad_tiled_kernel(StemWgradA
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#ifndef SW_EXP_NO_STAGE
         if (more) stage_store(next, buf ^ 1, stg);
         sw_barrier();
-#endif
         if (more) {       // slot 0 of the next chunk
             const float* __restrict__ nrows = sw_lds + (buf ^ 1) * buf_words;
 #pragma unroll
@@ -446,11 +429,7 @@ __global__ __launch_bounds__(SW_THREADS) void stem_wgrad_tiled_kernel(StemWgradA
         }
         pz = pzn; py = pyn;
     }
-#ifndef SW_EXP_NO_EPILOGUE
     sw_block_result(acc, sw_lds, a.part, wave, lane);
-#else
-    if (acc[0][0][0] == 123.f) a.part[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7] + acc[4][0][9];
-#endif
 }
 
 // dw [7][7][3][64] += the blocks' partials.  16 lanes per element, one batch of loads each (a single thread walking 256 partials
@@ -482,25 +461,24 @@ size_t sw_lds_bytes(int Wp) {
 }
 constexpr int SW_MAX_WP = 236;       // 6 staging loads per thread: clips up to 231 pixels wide
 
+// The dynamic-LDS limit of a kernel is a PER-DEVICE attribute: it is set before every launch (a host-side table update: a process
+// with handles on two GPUs, or two launching threads, must not find it unset -- ADVICE round 4; the launch itself is ~3 us of
+// host time, this call well under one).
 template <class K>
-hipError_t sw_launch_k(K kernel, size_t& attr, const StemWgradArgs& a, unsigned blocks, size_t lds, hipStream_t s) {
-    if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr = lds;
-    }
+hipError_t sw_launch_k(K kernel, const StemWgradArgs& a, unsigned blocks, size_t lds, hipStream_t s) {
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;       // one block may take the CU's whole LDS on gfx950, not more
+    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(SW_THREADS), lds, s, a);
     return hipGetLastError();
 }
 template <bool FUSED, int NST>
 hipError_t sw_launch(const StemWgradArgs& a, unsigned blocks, size_t lds, hipStream_t s) {
-    static size_t attr = 0;
-    return sw_launch_k(stem_wgrad_kernel<FUSED, NST>, attr, a, blocks, lds, s);
+    return sw_launch_k(stem_wgrad_kernel<FUSED, NST>, a, blocks, lds, s);
 }
 template <bool FUSED, int NST, int PER>
 hipError_t sw_launch_tiled(const StemWgradArgs& a, unsigned blocks, size_t lds, hipStream_t s) {
-    static size_t attr = 0;
-    return sw_launch_k(stem_wgrad_tiled_kernel<FUSED, NST, PER>, attr, a, blocks, lds, s);
+    return sw_launch_k(stem_wgrad_tiled_kernel<FUSED, NST, PER>, a, blocks, lds, s);
 }
 }  // namespace
 

@@ -304,3 +304,9 @@ class P3DSession:
     def comm_init(self, id_bytes):
         buf = C.create_string_buffer(bytes(id_bytes), _lib.P3D_COMM_ID_BYTES)
         check(lib().p3d_comm_init(self._h, buf))
+
+    def comm_info(self):
+        """(ranks, rank, device) as RCCL reports them for this handle's communicator; ranks == 0: no communicator."""
+        n, r, d = C.c_int(0), C.c_int(-1), C.c_int(-1)
+        check(lib().p3d_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)))
+        return n.value, r.value, d.value

@@ -125,3 +125,19 @@ def test_product_build_reads_only_its_documented_environment():
     hdr = open(os.path.join(ROOT, "sap3d_tensorflow_amd", "csrc", "p3d_kernels.h")).read()
     body = hdr[hdr.index("p3d_tune_env"):]
     assert re.search(r"#if defined\(P3D_TUNING\)\s+return getenv\(name\);\s+#else", body), "p3d_tune_env must be compiled out of the product build"
+
+
+def test_every_fill_and_copy_in_the_library_names_its_stream():
+    """A bare hipMemset / hipMemcpy (/ 2D) runs on the null stream, which is not ordered against the handle's non-blocking
+    streams: in rounds 3 and 4 such a call raced a launch (arrival counters zeroed under a running kernel; decision-hook
+    scratch zeroed while its gate kernels ran).  Every fill / copy in csrc/ goes through the *Async form with an explicit
+    stream (net.hip: fill_async, fill_now, copy_now); the allow-list is empty."""
+    import glob
+    import re
+    bad = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "sap3d_tensorflow_amd", "csrc", "*"))):
+        for i, line in enumerate(open(f, errors="replace"), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bhipMem(set|cpy)(2D|3D)?\s*\(", code) or re.search(r"\bhipMemcpy(DtoH|HtoD|DtoD)\s*\(", code):
+                bad.append("%s:%d: %s" % (os.path.basename(f), i, line.strip()))
+    assert not bad, bad

@@ -79,8 +79,10 @@ def test_single_rank_allreduce_is_identity(structure, bucket_mb, monkeypatch):
     def run(with_comm):
         s = P3DSession(structure, batch=shape[0], frames=shape[1], height=shape[2], width=shape[3], base=cfg.base,
                        blocks=cfg.blocks, seed=2)
+        assert s.comm_info()[0] == 0                     # no communicator yet
         if with_comm:
             s.comm_init(P3DSession.comm_unique_id())
+            assert s.comm_info() == (1, 0, 0)            # what RCCL says: one rank, rank 0, device 0 (bench.py's "rccl_ranks")
         losses = [np.float32(s.train_step(x, y, dropout=0.0)) for _ in range(3)]
         w = {n: s.get_param(n) for n, _, _ in s.variables()}
         s.close()

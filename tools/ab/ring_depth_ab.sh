@@ -1,5 +1,10 @@
 #!/bin/bash
 # A/B of the LDS-DMA ring depth of the 64-row igemm tiles (P3D_RING64: 3 stages = 48.5 KB per block, 4 = 64.5 KB, 5 = 80.5 KB)
+# whatever this script builds into the package directory, the PRODUCT build is back when it exits (build.py also keys its
+# object cache by the compile flags, so a later plain build would rebuild anyway)
+trap 'env -u P3D_EXTRA_HIPCC_FLAGS python -c "
+import sys; sys.path.insert(0, \".\")
+from sap3d_tensorflow_amd import build; build.build(force=True)" > /dev/null 2>&1' EXIT
 build() { P3D_EXTRA_HIPCC_FLAGS="-DP3D_TUNING -DP3D_RING64=$1" python -c "
 import sys; sys.path.insert(0,'.')
 from sap3d_tensorflow_amd import build; build.build(force=True)" > /dev/null 2>gpurun_out/ab/ring_build_$1.err || { echo "build $1 failed"; tail -5 gpurun_out/ab/ring_build_$1.err; exit 1; }; }

@@ -1,5 +1,10 @@
 #!/bin/bash
 # A/B: grouped filter-gradient launches on 64x128 tiles when every problem of the group has >= 2048 positions and 128-wide outputs
+# whatever this script builds into the package directory, the PRODUCT build is back when it exits (build.py also keys its
+# object cache by the compile flags, so a later plain build would rebuild anyway)
+trap 'env -u P3D_EXTRA_HIPCC_FLAGS python -c "
+import sys; sys.path.insert(0, \".\")
+from sap3d_tensorflow_amd import build; build.build(force=True)" > /dev/null 2>&1' EXIT
 P3D_EXTRA_HIPCC_FLAGS=-DP3D_TUNING python -c "
 import sys; sys.path.insert(0,'.')
 from sap3d_tensorflow_amd import build; build.build(force=True)" > /dev/null 2>&1 || { echo "tuning build failed"; exit 1; }
