@@ -151,13 +151,11 @@ def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a torch.distributed.run environment: start
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a child process on a free
     local port, pass its output through (rank 0 prints the ONE JSON line) and return its exit code."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: torch.distributed.run picks a free rendezvous port itself (a port found here by bind-and-close could be taken by
+    # another job on the host before the ranks bind it: ADVICE round 4); --local-addr: the container hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n),
+           os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.setdefault("OMP_NUM_THREADS", "1")
     return subprocess.run(cmd, env=env, cwd=ROOT).returncode

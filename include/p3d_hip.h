@@ -208,6 +208,10 @@ int p3d_debug_bucket_audit(p3d_handle* h, float dropout_rate, uint64_t seed, int
  * (every sliced launch re-zeroes its own: anything but 0 means a launch left the scratch dirty); -1 on a HIP error. */
 int64_t p3d_debug_dirty_counters(void);
 
+/* Test hook (process-wide): on SIGABRT / SIGSEGV print a C-level backtrace to stderr before dying, and the message of an uncaught
+ * C++ exception (tests/conftest.py installs it: Python's faulthandler shows Python frames only). */
+int p3d_debug_install_abort_trace(void);
+
 /* Test hook (process-wide): force the tile / K-slice plan of the convolution kernels where a problem allows it, so that
  * every instantiation is reachable from the op-level parity tests.  igemm_tile: 0 = 64x64, 1 = 128x64, 2 = 128x128,
  * -1 = the plan's choice; igemm_splits: K-slices, 0 = the plan's; wgrad_tm / wgrad_tn: 64 or 128, 0 = the plan's. */
@@ -224,6 +228,11 @@ int p3d_op_conv3d_backprop_filter(int device, const float* x, const int64_t xsha
 /* tf.layers.conv3d_transpose 'same'; kernel [kd,kh,kw,Cout,Cin] */
 int p3d_op_conv3d_transpose(int device, const float* x, const int64_t xshape[5], const float* k,
                             const int64_t kshape[5], const int s[3], const float* bias, float* y);
+/* Test hook: the stem's filter gradient through its BatchNorm + ReLU (tf.gradients of p3d.py:172-174 w.r.t. firstconv1), once with
+ * the normalisation's backward evaluated on the kernel's operand (what the train step runs) and once as two launches.  x [N,D,H,W,3];
+ * y, dz [N,D,ceil(H/2),ceil(W/2),64]; tab [5][64] = scale, shift, mean, invstd, gamma; coef [64][2]; both results [1,7,7,3,64]. */
+int p3d_debug_stem_wgrad_through_bn(int device, const float* x, const int64_t xshape[5], const float* y, const float* dz, const float* tab,
+                                    const float* coef, int batch, float* dw_fused, float* dw_two_launches);
 int p3d_op_max_pool3d(int device, const float* x, const int64_t xshape[5], const int ksize[3], const int s[3], float* y);
 int p3d_op_max_pool3d_grad(int device, const float* x, const int64_t xshape[5], const int ksize[3], const int s[3],
                            const float* dy, float* dx);

@@ -102,6 +102,8 @@ def test_bare_bench_command_starts_the_ranks_as_a_child(monkeypatch):
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    # the rendezvous: torch.distributed.run's own free-port choice on the loopback address (a port picked here by bind-and-close
+    # could be gone by the time the ranks bind it)
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in cmd
     assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "2"]
     assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")

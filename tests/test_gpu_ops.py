@@ -398,3 +398,45 @@ def test_gn_head_transposed_convs_at_full_width(xs, k, co, s):
     close(ops.conv3d(dy, kern, s), X.grad)
     close(ops.conv3d_backprop_filter(dy, kern.shape, x, s), K.grad)
     close(ops.bias_add_grad(dy), Bv.grad)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 30, 28), (2, 16, 112, 112), (1, 2, 224, 224)])
+@pytest.mark.parametrize("batch", [1, 0])
+def test_stem_filter_gradient_through_batchnorm_on_the_operand_path(shape, batch):
+    """stem_wgrad.hip's FUSED form (what the train step runs: firstconv1's filter gradient with the stem BatchNorm's backward apply
+    pass evaluated on the kernel's B operand, p3d.py:172-174) against the two-launch form -- bn_bwd_apply_kernel<0>, then the plain
+    one-pass filter gradient -- on the same inputs, AND against the float64 oracle of the two steps; batch statistics (the
+    coefficient terms) and moving statistics (c1 = c2 = 0); the generic variant (15 x 14 outputs) and the tiled ones (112, 224)."""
+    import ctypes as C
+    from sap3d_tensorflow_amd._lib import check, fptr, lib
+    rng = np.random.default_rng(sum(shape) + batch)
+    xs = shape + (3,)
+    x = rnd(rng, xs)
+    oshape = (xs[0], xs[1], (xs[2] + 1) // 2, (xs[3] + 1) // 2, 64)
+    y = rnd(rng, oshape)
+    dz = rnd(rng, oshape)
+    gamma = rng.uniform(0.5, 1.5, 64).astype(np.float32)
+    beta = rng.uniform(-0.3, 0.3, 64).astype(np.float32)
+    y64 = y.astype(np.float64).reshape(-1, 64)
+    mean = y64.mean(0) if batch else rng.uniform(-0.1, 0.1, 64)
+    var = y64.var(0) if batch else rng.uniform(0.5, 1.5, 64)
+    invstd = 1.0 / np.sqrt(var + 1e-3)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    xhat = (y64 - mean) * invstd
+    g = np.where(scale * y64 + shift > 0, dz.astype(np.float64).reshape(-1, 64), 0.0)
+    M = y64.shape[0]
+    c1, c2 = g.sum(0) / M, (g * xhat).sum(0) / M
+    dy = gamma * invstd * ((g - c1 - xhat * c2) if batch else g)
+    want = nn.conv3d_backward_filter(x.astype(np.float64), dy.reshape(oshape), (1, 7, 7, 3, 64), (1, 2, 2))
+    tab = np.stack([scale, shift, mean, invstd, gamma]).astype(np.float32)
+    coef = np.stack([c1, c2], axis=1).astype(np.float32)
+    fused = np.empty((1, 7, 7, 3, 64), np.float32)
+    two = np.empty_like(fused)
+    check(lib().p3d_debug_stem_wgrad_through_bn(0, fptr(x), (C.c_int64 * 5)(*xs), fptr(y), fptr(dz), fptr(np.ascontiguousarray(tab)),
+                                               fptr(np.ascontiguousarray(coef)), batch, fptr(fused), fptr(two)))
+    # the gate uses fp32 scale*y+shift on the GPU: an element within 1e-7 of zero may flip against float64; one element of ~1.6 M moves the
+    # sums by ~1e-6 of their magnitude, well inside the tolerance
+    close(two, want, 5e-5)
+    close(fused, want, 5e-5)
+    close(fused, two.astype(np.float64), 2e-6)
