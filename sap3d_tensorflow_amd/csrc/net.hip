@@ -21,6 +21,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -233,6 +234,42 @@ void launch(const Ctx& c, const char* kernel, double flops, double bytes, F&& f)
 }
 
 std::atomic<int> g_live_handles{0};      // p3d_create .. p3d_destroy; p3d_shutdown refuses while any is alive
+
+// ---- stream pool (round 5) ------------------------------------------------------------------------------------------------------
+// A handle needs three streams (main and comm at the highest priority, side at the lowest).  A process that opens and closes many
+// handles -- the test suite: ~250 sessions -- used to create and destroy three hardware queues per handle; the runtime releases
+// them lazily, and one full-suite run of round 5 died with a bare abort() inside p3d_create after 235 tests (no message, not
+// reproduced in two further runs).  Streams are now returned to a per-device, per-priority pool by p3d_destroy and taken from it
+// by p3d_create: a long-lived process keeps three queues per device however many handles it has seen, and the K-slice scratch,
+// which is keyed by stream, is reused with them instead of accumulating per session.  p3d_shutdown destroys the pooled streams.
+struct StreamPool {
+    std::mutex m;
+    std::map<std::pair<int, int>, std::vector<hipStream_t>> idle;      // (device, priority class: 0 highest, 1 lowest)
+};
+StreamPool& stream_pool() { static StreamPool p; return p; }
+hipStream_t take_stream(int device, int prio_class) {
+    {
+        std::lock_guard<std::mutex> g(stream_pool().m);
+        auto& v = stream_pool().idle[{device, prio_class}];
+        if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+    }
+    int least = 0, greatest = 0;
+    HIPCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s = nullptr;
+    HIPCHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_class == 0 ? greatest : least));
+    return s;
+}
+void give_stream(int device, int prio_class, hipStream_t s) {      // the stream must be idle (p3d_destroy synchronises the device first)
+    if (!s) return;
+    std::lock_guard<std::mutex> g(stream_pool().m);
+    stream_pool().idle[{device, prio_class}].push_back(s);
+}
+void destroy_pooled_streams() {
+    std::lock_guard<std::mutex> g(stream_pool().m);
+    for (auto& kv : stream_pool().idle)
+        for (hipStream_t s : kv.second) hipStreamDestroy(s);
+    stream_pool().idle.clear();
+}
 const float* g_zero_page = nullptr;      // 1 KiB of zeros (device), set by p3d_create / op entry points
 
 void igemm_work(const IgemmArgs& a, double& flops, double& bytes) {
@@ -614,6 +651,7 @@ void ensure_zero_page() {
 struct p3d_handle {
     p3d_config cfg;
     hipStream_t stream = nullptr, comm_stream = nullptr, side_stream = nullptr;
+    bool side_pooled = true;                  // false: created with a CU mask (tuning builds), destroyed with the handle
     std::vector<hipEvent_t> fork_events;
     hipEvent_t ev_side_done = nullptr, ev_side_bucket = nullptr;
     // Events that only order this handle's own streams on one device: no system-scope fence when they complete (the default
