@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libp3dhip.so")
-SOURCES = ["conv_igemm2.hip", "conv_wgrad2.hip", "stem_wgrad.hip", "elementwise.hip", "bn_small.hip", "gn.hip", "cbam.hip", "head.hip", "attention.hip", "attention_flash.hip", "metrics.hip", "net.hip"]
+SOURCES = ["conv_igemm2.hip", "conv_pointwise.hip", "conv_wgrad2.hip", "stem_wgrad.hip", "elementwise.hip", "bn_small.hip", "gn.hip", "cbam.hip", "head.hip", "attention.hip", "attention_flash.hip", "metrics.hip", "net.hip"]
 HEADERS = [os.path.join(CSRC, n) for n in ("p3d_kernels.h", "det_reduce.h", "igemm_epilogue.h", "net_ops.inc", "net_gn.inc", "net_graphs.inc", "net_plan.inc", "net_sched.inc", "net_abi.inc")] + [ os.path.join(os.path.dirname(HERE), "include", "p3d_hip.h")]
 # P3D_EXTRA_HIPCC_FLAGS: extra compile flags for A/B builds of the tuning macros (e.g. -DP3D_PF64=0), see tools/README.md
 FLAGS = (["-DP3D_SETPRIO"] if os.environ.get("P3D_SETPRIO") else []) + os.environ.get("P3D_EXTRA_HIPCC_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]

@@ -978,6 +978,11 @@ P3dIgemmPlan p3d_igemm2_plan(const IgemmArgs& a, int) {
     else if (ov.tile == 2 && a.Nc > 64) { pl.bm = 128; pl.bn = 128; }
     if (ov.splits >= 1 && ov.splits <= steps) pl.splits = ov.splits;
     pl.name = plan_name(pl.bm, pl.bn);
+    // dense 1x1x1 convs over many positions: the weights-resident streaming kernel (a forced tile / slice count keeps the tiled one)
+    if (ov.tile < 0 && ov.splits < 1) {
+        pl.stream_blocks = p3d_pw_stream_blocks(a);
+        if (pl.stream_blocks > 0) { pl.splits = 1; pl.name = "pw_stream_kernel"; }
+    }
     return pl;
 }
 
@@ -1007,6 +1012,7 @@ hipError_t p3d_launch_igemm2(const IgemmArgs& a0, const P3dIgemmPlan& pl, hipStr
     for (int q = 0; q < a.ngate; ++q)
         if (!a.gate[q].y || !a.gate[q].out || !a.gate[q].part || (a.gate[q].ldy & 3) || (a.gate[q].ldo & 3)) return hipErrorInvalidValue;
     if (a.ngate && a.statpart) return hipErrorInvalidValue;
+    if (pl.stream_blocks > 0) return p3d_launch_pw_stream(a, s);
     if (p3d_igemm2_tail_split(a, pl)) return p3d_launch_igemm2_group(&a, 1, pl, s);      // full rounds + a K-sliced tail class
     if (pl.bm == 128 && pl.bn == 128) return launch_t<128, 128>(a, pl, s);
     if (pl.bm == 128 && pl.bn == 64) return launch_t<128, 64>(a, pl, s);
@@ -1073,7 +1079,7 @@ hipError_t launch_group_t(IgemmGroupArgs& g, const long long* tiles, hipStream_t
 
 // Would the tail of this single launch be cut into K-slices (then it goes out through the grouped kernel)?
 bool p3d_igemm2_tail_split(const IgemmArgs& a, const P3dIgemmPlan& pl) {
-    if (a.at_mode || a.ngate || pl.splits > 1 || !tail_split_enabled()) return false;
+    if (a.at_mode || a.ngate || pl.splits > 1 || pl.stream_blocks > 0 || !tail_split_enabled()) return false;
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     const long long tiles = ((M + pl.bm - 1) / pl.bm) * ((a.Nc + pl.bn - 1) / pl.bn);
     const int steps = a.ntaps * ((a.K + BK - 1) / BK);

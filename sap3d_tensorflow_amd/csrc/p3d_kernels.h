@@ -204,9 +204,11 @@ struct IgemmGroupArgs {
 struct P3dIgemmPlan {
     int bm = 64, bn = 64, splits = 1;
     const char* name = "";
+    int stream_blocks = 0;      // > 0: the launch runs on the weights-resident streaming kernel (conv_pointwise.hip) with this many blocks
 };
 // number of output-tile rows (= statistics partials) a launch with this plan produces
 inline int p3d_igemm2_mtiles(const IgemmArgs& a, const P3dIgemmPlan& pl) {
+    if (pl.stream_blocks > 0) return pl.stream_blocks;      // one statistics partial per block
     const long long M = (long long)a.N * a.Gd * a.Gh * a.Gw;
     return (int)((M + pl.bm - 1) / pl.bm);
 }
@@ -258,6 +260,9 @@ bool p3d_igemm2_tail_split(const IgemmArgs& a, const P3dIgemmPlan& pl);      // 
 bool p3d_igemm2_groupable(const IgemmArgs* v, int n, const P3dIgemmPlan& plan);
 hipError_t p3d_launch_igemm2_group(const IgemmArgs* v, int n, const P3dIgemmPlan& plan, hipStream_t s);
 void p3d_igemm2_override(int tile, int splits);   // test / tools hook: force the tile (0: 64x64, 1: 128x64, 2: 128x128) and the K-slice count; -1 / 0 = no override
+// dense 1x1x1 convs over >= 16 384 positions with K * N <= 16 384 (conv_pointwise.hip): 0 = not that case, else the block count
+int p3d_pw_stream_blocks(const IgemmArgs& a);
+hipError_t p3d_launch_pw_stream(const IgemmArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad2(const WgradArgs& a, hipStream_t s);
 hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s);   // up to P3D_WGRAD_GROUP problems, one launch
 const char* p3d_wgrad2_variant(const WgradArgs& a);

@@ -285,16 +285,23 @@ def test_attention_core_forward_and_grads(B, ng, nf, ch):
     assert all(np.array_equal(a, b) for a, b in zip((o, dg, df, dh), again))
 
 
-def test_dense_pointwise_conv_at_stage1_size():
-    """A 1x1x1 conv over 50176 rows (conv3 of stage 1 at 8 clips of 16x112x112: 784 tiles of 128x128, two K steps each),
-    forward and input gradient against the oracle."""
+@pytest.mark.parametrize("xs,ci,co", [((8, 8, 28, 28), 64, 256), ((8, 8, 28, 28), 64, 64), ((2, 16, 32, 32), 64, 128),
+                                      ((8, 8, 28, 28), 256, 64), ((2, 8, 32, 33), 64, 256)])
+def test_dense_pointwise_conv_at_stage1_size(xs, ci, co):
+    """1x1x1 convs over >= 16384 rows (conv1 / conv3 / the projection of stage 1 at 8 clips of 16x112x112: 50176 rows), forward with
+    bias and input gradient against the oracle.  From 64 input channels the forward runs on the weights-in-registers streaming kernel
+    (conv_pointwise.hip), to 64 channels the input gradient does (the last case: 16896 rows = 528 slabs of 32 on 512 blocks); the others on
+    the tiled kernel -- same contract either way."""
     from sap3d_tensorflow_amd import ops
-    xs = (8, 8, 28, 28, 64)
+    xs = xs + (ci,)
     rng = np.random.default_rng(3)
     x = rnd(rng, xs)
-    w = rnd(rng, (1, 1, 1, 64, 256)) * 0.2
-    want = nn.conv3d_forward(x.astype(np.float64), w.astype(np.float64), (1, 1, 1))
-    close(ops.conv3d(x, w, (1, 1, 1)), want)
+    w = rnd(rng, (1, 1, 1, ci, co)) * 0.2
+    b = rnd(rng, (co,))
+    want = nn.conv3d_forward(x.astype(np.float64), w.astype(np.float64), (1, 1, 1)) + b.astype(np.float64)
+    got = ops.conv3d(x, w, (1, 1, 1), bias=b)
+    close(got, want)
+    assert np.array_equal(got, ops.conv3d(x, w, (1, 1, 1), bias=b))
     dy = rnd(rng, want.shape)
     close(ops.conv3d_backprop_input(xs, w, dy, (1, 1, 1)), nn.conv3d_backward_input(dy.astype(np.float64), w.astype(np.float64), (1, 1, 1), xs))
 

@@ -12,7 +12,7 @@ V="$ROOT/sap3d_tensorflow_amd/csrc/.variant_${name}_$unit.hip"; cp "$src" "$V"
 trap "rm -f $V" EXIT
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value "$@" -c "$V" -o $O/$unit.o
 objs=""
-for f in conv_igemm2 conv_wgrad2 stem_wgrad elementwise bn_small gn cbam head attention attention_flash metrics net; do
+for f in conv_igemm2 conv_pointwise conv_wgrad2 stem_wgrad elementwise bn_small gn cbam head attention attention_flash metrics net; do
   if [ $f = $unit ]; then objs="$objs $O/$unit.o"; else objs="$objs $B/$f.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/ab/libp3dhip_$name.so" $objs -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
