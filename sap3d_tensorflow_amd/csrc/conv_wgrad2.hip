@@ -827,6 +827,15 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
     for (auto* a : live) if (a->xt || a->dyt) fused = true;
     WPlan solo = live.size() == 1 ? plan(*live[0]) : WPlan{64, 64, 0, 1, 0.0};
     if (live.size() > 1 && group_takes_rect(live)) solo.tn = 128;
+    // tuning build: P3D_TUNE_WGRAD_GROUP_TILE = 1 / 2 / 3 puts the groups over few positions (the bottlenecks of stages 2-3) on 64x128 /
+    // 128x128 / 128x64 tiles (fewer, longer blocks that pull fewer operand bytes beside the main stream's chain)
+    static const int grp_tile = [] { const char* e = p3d_tune_env("P3D_TUNE_WGRAD_GROUP_TILE"); return e ? atoi(e) : 0; }();
+    if (grp_tile && live.size() > 1 && g_force_tm == 0) {
+        bool ok = true;
+        const int gtm = grp_tile >= 2 ? 128 : 64, gtn = grp_tile <= 2 ? 128 : 64;
+        for (auto* a : live) ok = ok && !a->pair && a->K % gtm == 0 && a->Nc % gtn == 0 && (long long)a->N * a->Gd * a->Gh * a->Gw <= wtune().polite_rows;
+        if (ok) { solo.tm = gtm; solo.tn = gtn; }
+    }
     const int tm = solo.tm, tn = solo.tn;
     long long tiles64_all = 0;
     for (auto* a : live) tiles64_all += tiles_of(*a, 64, 64);
@@ -847,6 +856,14 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
         kstride = std::max(kstride, p.ksplit);
     }
     g.kstride = kstride;       // slab of (slot, cut) = slot * kstride + cut: disjoint whatever each problem's cut count
+    static const bool trace = p3d_tune_env("P3D_TUNE_WGRAD_TRACE") != nullptr;      // tuning build: what a grouped launch is made of
+    if (trace) {
+        fprintf(stderr, "[p3d] wgrad group %dx%d, %lld blocks:", tm, tn, blocks);
+        for (size_t q = 0; q < live.size(); ++q)
+            fprintf(stderr, "  [M %lld K %d N %d taps %d cuts %d]", (long long)live[q]->N * live[q]->Gd * live[q]->Gh * live[q]->Gw, live[q]->K, live[q]->Nc,
+                    live[q]->ntaps, g.p[q].ksplit);
+        fprintf(stderr, "\n");
+    }
     if (blocks >= (1ll << 31)) return hipErrorInvalidValue;
     const long long slabs = kstride > 1 ? (long long)tile0 * kstride : 0;
     // Residency (launch_group_t): problems over few positions belong to the encoder's later stages, whose main-stream launches
