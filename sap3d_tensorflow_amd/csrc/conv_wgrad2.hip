@@ -839,16 +839,34 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
     const int tm = solo.tm, tn = solo.tn;
     long long tiles64_all = 0;
     for (auto* a : live) tiles64_all += tiles_of(*a, 64, 64);
+    // cuts per problem (the model of plan(): the launch's tiles on 512-768 slots, blocks of steps / cuts + overhead)
+    int cuts[P3D_WGRAD_GROUP];
+    long long steps_of[P3D_WGRAD_GROUP], shortest = 1ll << 60;
+    for (size_t q = 0; q < live.size(); ++q) {
+        const WgradArgs& a = *live[q];
+        const WPlan w = live.size() == 1 ? plan(a) : plan(a, tiles64_all - tiles_of(a, 64, 64));
+        cuts[q] = w.ks;
+        steps_of[q] = ((long long)a.N * a.Gd * a.Gh * a.Gw + BKM - 1) / BKM;
+        shortest = std::min(shortest, (steps_of[q] + cuts[q] - 1) / cuts[q]);
+    }
+    // A group may hold problems over different position counts (the queue packs across stage boundaries: five stage-2 problems and
+    // stage 1's projection gave 728 blocks of 28 steps beside 28 blocks of 224 -- 253 us at 28 TFLOP/s where its neighbours run at
+    // 75-80, round 5): a problem whose blocks would run more than twice the group's shortest is cut further, down to that length.
+    if (live.size() > 1)
+        for (size_t q = 0; q < live.size(); ++q) {
+            const long long len = (steps_of[q] + cuts[q] - 1) / cuts[q];
+            if (len <= 2 * shortest) continue;
+            const long long cap = std::max<long long>(1, std::min<long long>(steps_of[q] / 4, 64));
+            cuts[q] = (int)std::max<long long>(cuts[q], std::min(cap, (steps_of[q] + shortest - 1) / shortest));
+        }
     long long blocks = 0;
     int tile0 = 0, kstride = 1;
     for (size_t q = 0; q < live.size(); ++q) {
         const WgradArgs& a = *live[q];
         WProb& p = g.p[q];
         fill_prob(p, a);
-        const long long my64 = tiles_of(a, 64, 64);
-        const WPlan w = live.size() == 1 ? plan(a) : plan(a, tiles64_all - my64);
         const long long tiles = tiles_of(a, tm, tn);
-        p.ksplit = w.ks;
+        p.ksplit = cuts[q];
         p.blk0 = (int)blocks;
         p.tile0 = tile0;
         blocks += tiles * p.ksplit;

@@ -861,13 +861,6 @@ struct p3d_handle {
         static const int64_t flush_tiles = p3d_tune_env("P3D_WGRAD_FLUSH_TILES") ? atol(p3d_tune_env("P3D_WGRAD_FLUSH_TILES")) : 512;   // tuning: 256 -> 17.25 ms / step, 512 -> 17.0, 1024 with groups of 12 -> 17.1
         const bool alone = no_group || wgrad_tiles64(a) >= 256;      // fills the chip by itself (and may take 128x128 tiles)
         if (alone) flush_wgrads(c);
-        // a group holds problems over ONE position count: a launch's cuts are planned per problem for blocks of about equal length, and
-        // the stage-1 projection (50 176 positions) in a group of stage-2 problems (6 272) ran 224-step blocks beside 28-step ones
-        // (253 us at 28 TFLOP/s where its neighbours reach 75-80; round 5)
-        if (!wq.empty()) {
-            const WgradArgs& b = wq.back().a;
-            if ((double)b.N * b.Gd * b.Gh * b.Gw != M) flush_wgrads(c);
-        }
         wq.push_back(pw);
         int64_t tiles = 0;
         for (auto& q : wq) tiles += wgrad_tiles64(q.a);
