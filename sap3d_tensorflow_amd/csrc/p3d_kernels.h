@@ -16,7 +16,9 @@
 #include <stdint.h>
 
 #define P3D_MAX_TAPS 27
+#ifndef P3D_WGRAD_GROUP
 #define P3D_WGRAD_GROUP 6     // weight-gradient problems one grouped launch can carry (kernel-argument space)
+#endif
 #define P3D_STAT_REPLICAS 16   // lanes that share a channel's partial sums in the finalize kernels (fixed 4-step shuffle fold)
 #define P3D_FOLD_MAX 32        // fused BatchNorm: up to this many per-tile partials a consuming launch folds itself (else a finalize launch)
 
