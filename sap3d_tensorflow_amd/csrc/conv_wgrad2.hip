@@ -852,7 +852,8 @@ hipError_t p3d_launch_wgrad2_group(const WgradArgs* probs, int n, hipStream_t s)
     // A group may hold problems over different position counts (the queue packs across stage boundaries: five stage-2 problems and
     // stage 1's projection gave 728 blocks of 28 steps beside 28 blocks of 224 -- 253 us at 28 TFLOP/s where its neighbours run at
     // 75-80, round 5): a problem whose blocks would run more than twice the group's shortest is cut further, down to that length.
-    if (live.size() > 1)
+    static const bool no_balance = p3d_tune_env("P3D_TUNE_WGRAD_NO_BALANCE") != nullptr;      // A/B runs (tuning build)
+    if (live.size() > 1 && !no_balance)
         for (size_t q = 0; q < live.size(); ++q) {
             const long long len = (steps_of[q] + cuts[q] - 1) / cuts[q];
             if (len <= 2 * shortest) continue;
