@@ -749,8 +749,18 @@ void fill_prob(WProb& p, const WgradArgs& a) {
     }
 }
 
+__global__ void wgrad_nop_kernel(int) {}
+
 template <int BM, int BN, bool FUSED>
 hipError_t launch_group_t(WGroup& g, long long blocks, long long slabs, int slots, bool greedy, bool polite, hipStream_t s) {
+    // timing diagnostic (WRONG RESULTS, tuning build): P3D_TUNE_WGRAD_EMPTY=1 launches an empty kernel in place of every filter gradient --
+    // what the side stream's LAUNCHES (fork events, dispatches, end-of-kernel fences) cost the main stream without their work;
+    // =2: a grid of the real size whose blocks return at once
+    static const int empty = [] { const char* e = p3d_tune_env("P3D_TUNE_WGRAD_EMPTY"); return e ? atoi(e) : 0; }();
+    if (empty) {
+        hipLaunchKernelGGL(wgrad_nop_kernel, dim3(empty == 2 ? (unsigned)blocks : 1u), dim3(256), 0, s, 0);
+        return hipGetLastError();
+    }
     // LDS request = residency limiter.  The filter gradients share the chip with the main stream's chain of small launches,
     // whose blocks (igemm2 64x64: 48.5 KB of LDS) must find room on every CU while a filter-gradient launch is resident:
     // three 48 KB blocks per CU leave 16 KB, and every main-stream launch then waits for a filter-gradient block to
