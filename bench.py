@@ -161,6 +161,16 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env, cwd=ROOT).returncode
 
 
+def pick_device(local_rank, visible):
+    """The device ordinal of this rank: LOCAL_RANK when the launcher shows every rank all the node's GPUs (torch.distributed.run), 0 when it
+    shows each rank exactly one (per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES).  Anything else cannot give one GPU per rank."""
+    if visible > local_rank or visible < 0:          # (< 0: the runtime could not say -- the launcher's convention)
+        return local_rank
+    if visible == 1:
+        return 0
+    raise SystemExit("LOCAL_RANK %d but this process sees %d GPU(s): launch one rank per GPU" % (local_rank, visible))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,8 +214,8 @@ def main():
     # every rank uses device 0 and no RCCL communicator is built (RCCL refuses two ranks on one device), so gradients
     # stay local.  The printed value is meaningless and says so.
     rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1"
-    sess = P3DSession(args.structure, batch=B, frames=T, height=S, width=S, device=0 if rehearsal else local_rank,
-                      world_size=world, rank=rank, seed=1)
+    device = 0 if rehearsal else pick_device(local_rank, P3DSession.device_count())
+    sess = P3DSession(args.structure, batch=B, frames=T, height=S, width=S, device=device, world_size=world, rank=rank, seed=1)
     if args.pointwise == "fp16":
         sess.set_pointwise_fp16(True)
     if args.attention != "auto":
@@ -217,9 +227,9 @@ def main():
         sess.comm_init(plane.share_from_rank0(P3DSession.comm_unique_id))
         # what RCCL itself says: every rank must sit in ONE communicator of `world` ranks, with its own rank number, on its own GPU
         n, r, d = sess.comm_info()
-        if (n, r, d) != (world, rank, local_rank):
+        if (n, r, d) != (world, rank, device):
             raise SystemExit("rank %d: RCCL communicator has %d ranks (this one: %d, device %d), expected %d / %d / %d" %
-                             (rank, n, r, d, world, rank, local_rank))
+                             (rank, n, r, d, world, rank, device))
         rccl_ranks = n
     x = synthetic.synthetic_clip(rank, (B, T, S, S, 3))
     y = synthetic.synthetic_target(3 + rank, (B, T, S, S))

@@ -191,6 +191,10 @@ int p3d_profile_step(p3d_handle* h, float dropout_rate, uint64_t seed, p3d_op_ti
 #define P3D_COMM_ID_BYTES 128
 int p3d_comm_unique_id(void* id_out);
 int p3d_comm_init(p3d_handle* h, const void* id);
+/* GPUs this process can see (hipGetDeviceCount), -1 on error.  A launcher may give every rank ALL the node's GPUs (torch.distributed.run:
+ * rank r uses device LOCAL_RANK) or exactly one (per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES: every rank uses device 0);
+ * bench.py asks before it picks p3d_config.device. */
+int p3d_device_count(void);
 /* What RCCL itself says about the handle's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): *n_ranks = 0 when the
  * handle has none.  bench.py prints it as "rccl_ranks" at N > 1 and refuses a run where it differs from --gpus, so that a scaling
  * line cannot come from ranks that never met. */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "p3d_comm_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "p3d_debug_stem_wgrad_through_bn": (C.c_int, [C.c_int, _fp, C.POINTER(C.c_int64), _fp, _fp, _fp, _fp, C.c_int, _fp, _fp]),
     "p3d_debug_install_abort_trace": (C.c_int, []),
+    "p3d_device_count": (C.c_int, []),
     "p3d_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "p3d_debug_bucket_audit": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64, C.c_int64, _i64p, _i64p, C.POINTER(C.c_int32), C.c_int,
                                          _i64p, _i64p]),

@@ -296,6 +296,11 @@ class P3DSession:
 
     # ---- data parallel -----------------------------------------------------------------------------
     @staticmethod
+    def device_count():
+        """GPUs visible to this process (-1: the runtime could not say)."""
+        return lib().p3d_device_count()
+
+    @staticmethod
     def comm_unique_id():
         buf = C.create_string_buffer(_lib.P3D_COMM_ID_BYTES)
         check(lib().p3d_comm_unique_id(buf))

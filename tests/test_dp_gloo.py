@@ -107,3 +107,18 @@ def test_bare_bench_command_starts_the_ranks_as_a_child(monkeypatch):
     assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in cmd
     assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "2"]
     assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+
+
+def test_rank_to_device_under_both_launcher_conventions():
+    """bench.py's device choice: LOCAL_RANK when every rank sees all the node's GPUs (torch.distributed.run), 0 when the launcher
+    shows each rank exactly one; anything else cannot give one GPU per rank and must stop the run."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert [bench.pick_device(r, 8) for r in range(8)] == list(range(8))
+    assert [bench.pick_device(r, 1) for r in range(8)] == [0] * 8
+    assert bench.pick_device(2, -1) == 2
+    try:
+        bench.pick_device(3, 2)
+        raise AssertionError("two visible GPUs cannot serve LOCAL_RANK 3")
+    except SystemExit:
+        pass
