@@ -1,7 +1,24 @@
 """Control plane of data-parallel runs: one process per GPU, torch.distributed (gloo) only ships the
 RCCL unique id and brackets timed regions; the gradient all-reduce itself runs inside libp3dhip
 (RCCL on a side stream).  The reference is single-device (train.py:73): nothing to mirror."""
+import contextlib
 import os
+import sys
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """gloo's C++ side announces its connections on file descriptor 1 ("[Gloo] Rank 0 is connected to 7 peer ranks"); a bench run's
+    standard output is ONE JSON line, so whatever the rendezvous prints goes to standard error."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 class Plane:
@@ -16,7 +33,9 @@ class Plane:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+            with _stdout_to_stderr():
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+                dist.barrier()          # the full mesh connects (and says so) at the first collective
             self.dist = dist
 
     def share_from_rank0(self, make):

@@ -122,3 +122,19 @@ def test_rank_to_device_under_both_launcher_conventions():
         raise AssertionError("two visible GPUs cannot serve LOCAL_RANK 3")
     except SystemExit:
         pass
+
+
+def test_rendezvous_keeps_standard_output_clean():
+    """A bench run prints ONE JSON line on standard output; gloo's C++ side announces its connections on file descriptor 1
+    ("[Gloo] Rank 0 is connected to 1 peer ranks"): Plane() sends whatever the rendezvous prints to standard error."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); from sap3d_tensorflow_amd.dp import Plane; "
+            "p = Plane(); print('LINE', p.rank); p.close()" % ROOT)
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                                       MASTER_PORT=str(port))) for r in range(2)]
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-2000:]
+        assert out == "LINE %d\n" % r, out
